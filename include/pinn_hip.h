@@ -1,0 +1,153 @@
+/*
+ * pinn_hip.h — C-ABI of libpinn_hip.so, the MI355X (gfx950) engine for the
+ * PINN depth-inversion hot path: tanh-MLP forward + first-order input-Jacobian
+ * ("jet") + PDE residual loss + parameter gradient.
+ *
+ * The reference (rezasalatin/PINN_depthEstimation) has no FFI; its boundary is
+ * the Python call surface.  Every entry point below names the reference code it
+ * replaces (file:line under /root/reference):
+ *
+ *   pinn_forward            dnn.py:54-55          DNN.forward (nn.Sequential of Linear/Tanh)
+ *   pinn_forward_jet        dnn.py:54-55 + physics.py:6-15   forward plus every
+ *                           compute_gradient(out_c, in_j) column in one pass
+ *   pinn_jet_backward       the double-backward torch runs under loss.backward()
+ *                           (train.py:191) for a generic consumer of the jet
+ *   pinn_residual_loss[_grad] physics.py:18-33,37-47,50-88,91-120 (continuity_only,
+ *                           continuity_ftemp, Navier_Stokes, physics_equation)
+ *                           fused with loss.backward() (train.py:154,191)
+ *   pinn_mse_loss_grad      train.py:131-141 (weighted fidelity MSE) + backward
+ *   pinn_adam_step          torch.optim.Adam.step as called at train.py:192
+ *
+ * Conventions
+ *   - plain C, no exceptions; every function returns 0 on success, <0 on error;
+ *     pinn_last_error() returns a thread-local message for the last failure.
+ *   - every pointer named params/X/Y/dY/T/grad/... is a DEVICE pointer owned by
+ *     the caller; the library allocates nothing that outlives a call.
+ *   - params: flat fp32 [W_0, b_0, W_1, b_1, ... W_L, b_L]; W_l is (out_l, in_l)
+ *     row-major — torch's nn.Linear.weight layout, state_dict order
+ *     layers.layer_{l}.weight / .bias (dnn.py:32-35).
+ *   - X: (N, d_in) row-major fp32 (what torch.cat([... (N,1) ...], -1) yields,
+ *     train.py:132,148).  Y: (N, d_out) row-major.  dY: (k, N, d_out): dY[j] is
+ *     d Y / d X[:, dir_col[j]] per point.
+ *   - stream: a hipStream_t passed as void* (torch's current stream).  Calls only
+ *     enqueue work; they never synchronise the device or the stream.
+ *   - workspace: query with pinn_query_workspace, allocate once, pass to calls.
+ */
+#ifndef PINN_HIP_H
+#define PINN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PINN_ABI_VERSION 1
+
+#define PINN_MAX_DIRS 3   /* tangent directions (inputs with requires_grad) */
+#define PINN_MAX_ROLES 8
+
+/* activation (dnn.py:18-21) */
+#define PINN_ACT_TANH 0        /* init_type == 'xavier'  */
+#define PINN_ACT_LEAKY_RELU 1  /* init_type == 'kaiming', negative_slope 0.01 */
+
+/* engine selector (0 lets the library pick the fastest kernel that supports the shape) */
+#define PINN_ENGINE_AUTO 0
+#define PINN_ENGINE_GENERIC 1  /* layer-by-layer VALU kernels, any shape */
+#define PINN_ENGINE_FUSED 2    /* MFMA chain kernel, hidden width <= 64 */
+
+/* error codes */
+#define PINN_OK 0
+#define PINN_ERR_INVALID (-1)
+#define PINN_ERR_UNSUPPORTED (-2)
+#define PINN_ERR_WORKSPACE (-3)
+#define PINN_ERR_LAUNCH (-4)
+
+typedef struct pinn_desc {
+  int32_t d_in;       /* config layers.input_features  (train.py:52) */
+  int32_t d_out;      /* config layers.output_features (train.py:55) */
+  int32_t n_hidden;   /* config layers.hidden_layers   (train.py:53) */
+  int32_t width;      /* config layers.hidden_width    (train.py:54) */
+  int32_t k;          /* number of inputs with requires_grad "true" (train.py:87) */
+  int32_t dir_col[PINN_MAX_DIRS]; /* X column of tangent direction j */
+  int32_t activation; /* PINN_ACT_* */
+  int32_t engine;     /* PINN_ENGINE_* */
+} pinn_desc;
+
+/* residual ids */
+#define PINN_RES_NAVIER_STOKES 1     /* physics.py:50-88  roles out: h,z,u,v   dirs: t,x,y */
+#define PINN_RES_PHYSICS_EQUATION 2  /* physics.py:91-120 roles out: h,U,V,eta_mean,Hrms,k  dirs: x,y */
+#define PINN_RES_CONTINUITY_FTEMP 3  /* physics.py:37-47  roles out: h,U,V     dirs: x,y */
+#define PINN_RES_CONTINUITY_ONLY 4   /* physics.py:18-33  same + h anchor where x < 25.5 */
+
+/* number of loss terms each residual reports (sums of squares, un-normalised) */
+#define PINN_NS_TERMS 3   /* sum fc^2, sum fm_x^2, sum fm_y^2 */
+#define PINN_PE_TERMS 3   /* sum fc^2, sum fx^2,  sum fy^2  */
+#define PINN_CF_TERMS 1   /* sum fc^2 */
+#define PINN_CO_TERMS 3   /* sum fc^2, sum_{x<thr} (h-anchor)^2, count{x<thr} */
+
+typedef struct pinn_residual_spec {
+  int32_t residual_id;
+  int32_t out_col[PINN_MAX_ROLES]; /* output column of each role, in the role order above */
+  int32_t dir_of[PINN_MAX_DIRS];   /* index into desc.dir_col of each direction role */
+  int32_t flags;                   /* bit0: 1 = "corrected" radiation stress (unused; E==0 bug-compatible, physics.py:106) */
+  float param[4];                  /* continuity_only: param[0]=threshold (25.5), param[1]=anchor (0.75) */
+} pinn_residual_spec;
+
+int32_t pinn_version(void);
+const char* pinn_last_error(void);
+
+/* P = sum_l (in_l*out_l + out_l), layers = [d_in] + [width]*n_hidden + [d_out] (train.py:56) */
+int32_t pinn_param_count(const pinn_desc* desc, int64_t* count);
+
+/* bytes of workspace a call on N points needs with the engine desc->engine selects.
+ * pinn_jet_backward always runs on the generic engine: query with
+ * engine = PINN_ENGINE_GENERIC for it. */
+int32_t pinn_query_workspace(const pinn_desc* desc, int64_t N, int64_t* bytes);
+
+int32_t pinn_forward(const pinn_desc* desc, const float* params, const float* X, int64_t N,
+                     float* Y, void* ws, int64_t ws_bytes, void* stream);
+
+int32_t pinn_forward_jet(const pinn_desc* desc, const float* params, const float* X, int64_t N,
+                         float* Y, float* dY, void* ws, int64_t ws_bytes, void* stream);
+
+/* grad_flat (P,) += d/dtheta [ sum(gY*Y) + sum(gdY*dY) ];  gdY may be NULL (treated as 0) */
+int32_t pinn_jet_backward(const pinn_desc* desc, const float* params, const float* X, int64_t N,
+                          const float* gY, const float* gdY, float* grad_flat,
+                          void* ws, int64_t ws_bytes, void* stream);
+
+/* term_sums[t] = sum over points of (residual field t)^2  (device, n_terms floats, overwritten) */
+int32_t pinn_residual_loss(const pinn_desc* desc, const pinn_residual_spec* spec,
+                           const float* params, const float* X, int64_t N,
+                           float* term_sums, void* ws, int64_t ws_bytes, void* stream);
+
+/* as above, and grad_flat (P,) += sum_t term_scale[t] * d term_sums[t] / d theta.
+ * term_scale is a DEVICE array (n_terms floats) so that a data-dependent
+ * normaliser (continuity_only's count, a global N under data parallelism) never
+ * needs a host round trip.  For mean-of-squares losses term_scale[t] = weight/N. */
+int32_t pinn_residual_loss_grad(const pinn_desc* desc, const pinn_residual_spec* spec,
+                                const float* term_scale,
+                                const float* params, const float* X, int64_t N,
+                                float* term_sums, float* grad_flat,
+                                void* ws, int64_t ws_bytes, void* stream);
+
+/* fidelity: col_sums[j] = sum_n (T[n,j] - Y[n,out_col[j]])^2 ;
+ * grad_flat += sum_j col_scale[j] * d col_sums[j] / d theta   (train.py:136-141).
+ * T is (N, n_cols) row-major; out_col is a HOST array; col_scale/col_sums are device. */
+int32_t pinn_mse_loss_grad(const pinn_desc* desc, const float* params, const float* X,
+                           const float* T, int64_t N, int32_t n_cols, const int32_t* out_col,
+                           const float* col_scale, float* col_sums, float* grad_flat,
+                           void* ws, int64_t ws_bytes, void* stream);
+
+/* torch.optim.Adam single-tensor update on flat buffers (amsgrad off, weight_decay 0,
+ * maximize off): m,v are exp_avg / exp_avg_sq; step is the 1-based step count;
+ * lr is a host double (StepLR changes it between steps, train.py:193); the scalar
+ * factors are formed in double as Python forms them and cast to fp32 once. */
+int32_t pinn_adam_step(float* params, const float* grad, float* m, float* v, int64_t P,
+                       int64_t step, double lr, double beta1, double beta2, double eps,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PINN_HIP_H */

@@ -1,0 +1,280 @@
+"""pinn_oracle — CPU restatement of the reference hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product package (pinn_depthestimation_amd) never does.
+
+What it restates (file:line under the reference tree):
+  * MLP construction / init / forward ............ dnn.py:7-55
+  * compute_gradient (reverse-mode VJP with ones) . physics.py:6-15
+  * continuity_only / continuity_ftemp ............ physics.py:18-33, 37-47
+  * Navier_Stokes ................................. physics.py:50-88
+  * physics_equation .............................. physics.py:91-120
+  * loss_func arithmetic (fidelity + residual) .... train.py:131-157,
+                                                   train_newmethod.py:129-159
+  * Adam + StepLR loop, LBFGS closure ............. train.py:100-125,185-200
+
+The arithmetic lives in PyTorch (un-vendored, un-pinned by the reference), so the
+restatement keeps the reference's formulation — N reverse passes with
+create_graph=True, then a double backward — written in our own words, dtype
+generic (fp32 to mirror the reference, fp64 as a high-precision referee).
+
+Pinning: tests/golden/*.npz were produced by tests/golden/make_goldens.py, which
+imports the reference's own dnn.py / physics.py in the build container; the
+tests check this oracle against those vectors (tests/test_oracle_golden.py).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Sequence
+
+import torch
+
+# ----------------------------------------------------------------------------- network
+
+
+def layer_sizes(d_in: int, n_hidden: int, width: int, d_out: int) -> List[int]:
+    """train.py:56 — [input_features] + [hidden_width]*hidden_layers + [output_features]."""
+    return [d_in] + [width] * n_hidden + [d_out]
+
+
+def init_params(layers: Sequence[int], init_type: str = "xavier", generator=None,
+                dtype=torch.float32) -> List[torch.Tensor]:
+    """dnn.py:27-52 — per Linear: weight (out,in) Xavier/Kaiming-uniform; bias zero on
+    every layer but the last, which keeps nn.Linear's default U(+-1/sqrt(fan_in))."""
+    if init_type not in ("xavier", "kaiming"):
+        raise ValueError(f"Invalid init_type: {init_type}. Use 'kaiming' or 'xavier'.")
+    params = []
+    n_lin = len(layers) - 1
+    for i in range(n_lin):
+        fan_in, fan_out = layers[i], layers[i + 1]
+        w = torch.empty(fan_out, fan_in, dtype=torch.float32)
+        if init_type == "xavier":
+            bound = math.sqrt(6.0 / (fan_in + fan_out))            # xavier_uniform_, gain 1
+        else:
+            gain = math.sqrt(2.0 / (1 + 0.01 ** 2))                # kaiming_uniform_(leaky_relu, a=0 -> slope .01)
+            bound = gain * math.sqrt(3.0 / fan_in)
+        w.uniform_(-bound, bound, generator=generator)
+        if i < n_lin - 1:
+            b = torch.zeros(fan_out, dtype=torch.float32)
+        else:
+            b = torch.empty(fan_out, dtype=torch.float32).uniform_(
+                -1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in), generator=generator)
+        params += [w.to(dtype), b.to(dtype)]
+    return params
+
+
+def params_from_state_dict(sd: Dict[str, torch.Tensor], dtype=torch.float32) -> List[torch.Tensor]:
+    """state_dict keys layers.layer_{i}.weight / .bias (dnn.py:35) -> [W0, b0, W1, b1, ...]."""
+    n = len([k for k in sd if k.endswith(".weight")])
+    out = []
+    for i in range(n):
+        out.append(torch.as_tensor(sd[f"layers.layer_{i}.weight"]).to(dtype).clone())
+        out.append(torch.as_tensor(sd[f"layers.layer_{i}.bias"]).to(dtype).clone())
+    return out
+
+
+def flatten(params: Sequence[torch.Tensor]) -> torch.Tensor:
+    return torch.cat([p.reshape(-1) for p in params])
+
+
+def unflatten(flat: torch.Tensor, layers: Sequence[int]) -> List[torch.Tensor]:
+    out, off = [], 0
+    for i in range(len(layers) - 1):
+        nw = layers[i] * layers[i + 1]
+        out.append(flat[off:off + nw].reshape(layers[i + 1], layers[i])); off += nw
+        out.append(flat[off:off + layers[i + 1]]); off += layers[i + 1]
+    return out
+
+
+def mlp_forward(params: Sequence[torch.Tensor], x: torch.Tensor, init_type: str = "xavier") -> torch.Tensor:
+    """dnn.py:54-55 with dropout p = 0: Linear -> act, last Linear bare."""
+    n_lin = len(params) // 2
+    a = x
+    for i in range(n_lin):
+        a = torch.nn.functional.linear(a, params[2 * i], params[2 * i + 1])
+        if i < n_lin - 1:
+            a = torch.tanh(a) if init_type == "xavier" else torch.nn.functional.leaky_relu(a, 0.01)
+    return a
+
+
+# ----------------------------------------------------------------------------- physics
+
+
+def compute_gradient(pred: torch.Tensor, var: torch.Tensor) -> torch.Tensor:
+    """physics.py:6-15 — d pred / d var per point, kept differentiable."""
+    (g,) = torch.autograd.grad(pred, var, grad_outputs=torch.ones_like(pred),
+                               retain_graph=True, create_graph=True)
+    return g
+
+
+def continuity_fields(x, y, h, U, V):
+    """physics.py:20-23 / 39-42"""
+    return compute_gradient(h * U, x) + compute_gradient(h * V, y)
+
+
+def continuity_ftemp(x, y, h, U, V):
+    """physics.py:37-47"""
+    fc = continuity_fields(x, y, h, U, V)
+    return torch.mean(fc ** 2)
+
+
+def continuity_only(x, y, h, U, V, threshold: float = 25.5, anchor: float = 0.75):
+    """physics.py:18-33 — adds mean((h[x<25.5] - 0.75)^2)."""
+    fc = continuity_fields(x, y, h, U, V)
+    idx = torch.where(x < threshold)
+    return torch.mean(fc ** 2) + torch.mean((h[idx] - anchor) ** 2)
+
+
+def navier_stokes_fields(t, x, y, h, z, u, v):
+    """physics.py:52-83 — the three residual fields (fc, fm_x, fm_y)."""
+    u_t, u_x, u_y = compute_gradient(u, t), compute_gradient(u, x), compute_gradient(u, y)
+    v_t, v_x, v_y = compute_gradient(v, t), compute_gradient(v, x), compute_gradient(v, y)
+    z_t, z_x, z_y = compute_gradient(z, t), compute_gradient(z, x), compute_gradient(z, y)
+    H = h + z
+    H_x, H_y = compute_gradient(H, x), compute_gradient(H, y)
+    Hu_x, Hv_y = compute_gradient(H * u, x), compute_gradient(H * v, y)
+    g, gamma_b = 9.81, 0.78
+    cb = 3.0 / 16.0 * g * gamma_b ** 2
+    fbr_x = cb * H_x * H
+    fbr_y = cb * H_y * H
+    fc = z_t + Hu_x + Hv_y
+    fm_x = u_t + u * u_x + v * u_y + g * z_x + 0 + fbr_x
+    fm_y = v_t + u * v_x + v * v_y + g * z_y + 0 + fbr_y
+    return fc, fm_x, fm_y
+
+
+def navier_stokes(t, x, y, h, z, u, v):
+    """physics.py:50-88"""
+    fc, fm_x, fm_y = navier_stokes_fields(t, x, y, h, z, u, v)
+    return torch.mean(fc ** 2) + torch.mean(fm_x ** 2) + torch.mean(fm_y ** 2)
+
+
+def physics_equation_fields(x, y, h, U, V, eta_mean, Hrms, k):
+    """physics.py:93-115, keeping the operator-precedence bug of :106
+    (E = 1/8**rho*g*Hrms**2 == 0.0) so the radiation-stress terms are exact zeros."""
+    u_x, u_y = compute_gradient(U, x), compute_gradient(U, y)
+    v_x, v_y = compute_gradient(V, x), compute_gradient(V, y)
+    z_x, z_y = compute_gradient(eta_mean, x), compute_gradient(eta_mean, y)
+    g, rho, cd = 9.81, 1025, 0.002
+    tau_bx = rho * cd * U * abs(U)
+    tau_by = rho * cd * V * abs(V)
+    E = 1 / 8 ** rho * g * Hrms ** 2            # == 0 * Hrms**2
+    Sxx = E * (2 * k * h / torch.sinh(2 * k * h) + 0.5)
+    Syy = E * (1 * k * h / torch.sinh(2 * k * h) + 0.0)
+    Sxx_x, Syy_y = compute_gradient(Sxx, x), compute_gradient(Syy, y)
+    inv = 1 / (rho * (eta_mean + h))
+    fc = u_x + v_y
+    fx = U * u_x + V * u_y + g * z_x + inv * (Sxx_x + 0) + inv * tau_bx
+    fy = U * v_x + V * v_y + g * z_y + inv * (0 + Syy_y) + inv * tau_by
+    return fc, fx, fy
+
+
+def physics_equation(x, y, h, U, V, eta_mean, Hrms, k):
+    """physics.py:91-120"""
+    fc, fx, fy = physics_equation_fields(x, y, h, U, V, eta_mean, Hrms, k)
+    return torch.mean(fc ** 2) + torch.mean(fx ** 2) + torch.mean(fy ** 2)
+
+
+RESIDUALS = {
+    "Navier_Stokes": navier_stokes,
+    "physics_equation": physics_equation,
+    "continuity_ftemp": continuity_ftemp,
+    "continuity_only": continuity_only,
+}
+
+# ----------------------------------------------------------------------------- losses
+
+
+def split_columns(X: torch.Tensor, grad_cols: Sequence[int]) -> List[torch.Tensor]:
+    """train.py:86-88 — one (N,1) tensor per input column; requires_grad per config."""
+    cols = []
+    for i in range(X.shape[1]):
+        c = X[:, i:i + 1].clone()
+        if i in grad_cols:
+            c.requires_grad_(True)
+        cols.append(c)
+    return cols
+
+
+def residual_loss(params, X, residual: str, in_roles: Sequence[int], out_roles: Sequence[int],
+                  grad_cols: Sequence[int], init_type="xavier"):
+    """train.py:144-154: cat columns -> dnn -> slice (N,1) outputs -> residual fn.
+    in_roles / out_roles give the X / Y column of each positional argument."""
+    cols = split_columns(X, grad_cols)
+    Y = mlp_forward(params, torch.cat(cols, dim=-1), init_type)
+    ins = [cols[i] for i in in_roles]
+    outs = [Y[:, o:o + 1] for o in out_roles]
+    return RESIDUALS[residual](*ins, *outs)
+
+
+def fidelity_loss(params, X, T, out_cols: Sequence[int], weights: Sequence[float], init_type="xavier"):
+    """train.py:131-141 — sum_k w_k * mean((true_k - pred_k)^2)."""
+    Y = mlp_forward(params, X, init_type)
+    total = 0
+    for j, (o, w) in enumerate(zip(out_cols, weights)):
+        total = total + w * torch.mean((T[:, j:j + 1] - Y[:, o:o + 1]) ** 2)
+    return total
+
+
+def flat_grad(loss: torch.Tensor, params: Sequence[torch.Tensor]) -> torch.Tensor:
+    gs = torch.autograd.grad(loss, list(params), allow_unused=True)
+    return torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(gs, params)])
+
+
+def jet(params, X, grad_cols: Sequence[int], init_type="xavier"):
+    """All compute_gradient(out_c, in_j) columns: returns Y (N,d_out), dY (k,N,d_out)."""
+    cols = split_columns(X, grad_cols)
+    Y = mlp_forward(params, torch.cat(cols, dim=-1), init_type)
+    dY = torch.stack([torch.cat([compute_gradient(Y[:, c:c + 1], cols[j]) for c in range(Y.shape[1])], dim=1)
+                      for j in grad_cols])
+    return Y.detach(), dY.detach()
+
+
+# ----------------------------------------------------------------------------- training loop
+
+
+def make_closure(params, loss_fn):
+    """train.py:195-199 — zero grads, loss, backward, return loss."""
+    def closure():
+        for p in params:
+            p.grad = None
+        loss = loss_fn()
+        loss.backward()
+        return loss
+    return closure
+
+
+def adam_trajectory(params, loss_fn, steps: int, lr: float, step_size: int = 10000, gamma: float = 0.8):
+    """train.py:188-193 — Adam(lr) + StepLR stepped every iteration.  Returns the loss list."""
+    params = [p.detach().clone().requires_grad_(True) for p in params]
+    opt = torch.optim.Adam(params, lr=lr)
+    sch = torch.optim.lr_scheduler.StepLR(opt, step_size=step_size, gamma=gamma)
+    losses = []
+    for _ in range(steps):
+        opt.zero_grad()
+        loss = loss_fn(params)
+        loss.backward()
+        opt.step()
+        sch.step()
+        losses.append(float(loss.detach()))
+    return losses, [p.detach() for p in params]
+
+
+def lbfgs_trajectory(params, loss_fn, max_iter: int, lr=1.0, max_eval=None, history_size=100,
+                     tolerance_grad=1e-5, tolerance_change=1e-7, line_search_fn="strong_wolfe"):
+    """train.py:116-125,195-200 — ONE LBFGS.step(closure); returns every closure loss."""
+    params = [p.detach().clone().requires_grad_(True) for p in params]
+    opt = torch.optim.LBFGS(params, lr=lr, max_iter=max_iter, max_eval=max_eval, history_size=history_size,
+                            tolerance_grad=tolerance_grad, tolerance_change=tolerance_change,
+                            line_search_fn=line_search_fn)
+    losses = []
+
+    def closure():
+        opt.zero_grad()
+        loss = loss_fn(params)
+        loss.backward()
+        losses.append(float(loss.detach()))
+        return loss
+
+    opt.step(closure)
+    return losses, [p.detach() for p in params]

@@ -1,0 +1,69 @@
+// common.h — shared host/device declarations for libpinn_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/pinn_hip.h"
+
+namespace pinn {
+
+void set_error(const char* fmt, ...);
+
+// layer geometry helpers: layers = [d_in] + [width]*n_hidden + [d_out] (train.py:56)
+struct Net {
+  int d_in, d_out, L /*hidden layers*/, W, k, K1, act;
+  int dir_col[PINN_MAX_DIRS];
+  int n_lin;  // L + 1 linear layers
+  __host__ __device__ int in_dim(int l) const { return l == 0 ? d_in : W; }
+  __host__ __device__ int out_dim(int l) const { return l == L ? d_out : W; }
+  __host__ __device__ int64_t w_off(int l) const {  // offset of W_l in the flat parameter vector
+    int64_t off = 0;
+    for (int i = 0; i < l; ++i) off += (int64_t)in_dim(i) * out_dim(i) + out_dim(i);
+    return off;
+  }
+  __host__ __device__ int64_t b_off(int l) const { return w_off(l) + (int64_t)in_dim(l) * out_dim(l); }
+  __host__ __device__ int64_t n_params() const { return w_off(L + 1); }
+};
+
+int make_net(const pinn_desc* d, Net* n);  // validates, returns PINN_OK or error
+
+// what a loss call asks the engines for
+struct LossReq {
+  int kind;  // 0 = residual, 1 = mse
+  pinn_residual_spec spec;
+  // mse
+  const float* T; int n_cols; int out_col[PINN_MAX_ROLES];
+  const float* scale;   // device: term_scale / col_scale (may be null when !want_grad)
+  float* sums;          // device: term_sums / col_sums
+  float* grad;          // device flat grad (+=) or null
+  int n_terms;
+};
+
+// generic engine (pinn_generic.hip)
+int64_t generic_workspace_bytes(const Net& n, int64_t N);
+int generic_forward(const Net& n, const float* params, const float* X, int64_t N, float* Y, float* dY,
+                    void* ws, int64_t ws_bytes, hipStream_t s);
+int generic_jet_backward(const Net& n, const float* params, const float* X, int64_t N, const float* gY,
+                         const float* gdY, float* grad, void* ws, int64_t ws_bytes, hipStream_t s);
+int generic_loss(const Net& n, const LossReq& rq, const float* params, const float* X, int64_t N,
+                 void* ws, int64_t ws_bytes, hipStream_t s);
+
+// fused MFMA engine (pinn_fused.hip)
+bool fused_supports(const Net& n);
+int64_t fused_workspace_bytes(const Net& n, int64_t N);
+int fused_forward(const Net& n, const float* params, const float* X, int64_t N, float* Y, float* dY,
+                  void* ws, int64_t ws_bytes, hipStream_t s);
+int fused_loss(const Net& n, const LossReq& rq, const float* params, const float* X, int64_t N,
+               void* ws, int64_t ws_bytes, hipStream_t s);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return PINN_ERR_LAUNCH;
+  }
+  return PINN_OK;
+}
+
+}  // namespace pinn

@@ -1,0 +1,226 @@
+// pinn_abi.hip — extern "C" entry points of libpinn_hip.so (see include/pinn_hip.h)
+// and the engine dispatch.  No torch types, no exceptions, no allocation.
+#include <string.h>
+#include "common.h"
+
+namespace pinn {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int make_net(const pinn_desc* d, Net* n) {
+  if (!d) { set_error("desc is NULL"); return PINN_ERR_INVALID; }
+  if (d->d_in < 1 || d->d_out < 1 || d->n_hidden < 1 || d->width < 1) {
+    set_error("bad network shape d_in=%d d_out=%d hidden=%d width=%d", d->d_in, d->d_out, d->n_hidden, d->width);
+    return PINN_ERR_INVALID;
+  }
+  if (d->k < 0 || d->k > PINN_MAX_DIRS) { set_error("k=%d outside 0..%d", d->k, PINN_MAX_DIRS); return PINN_ERR_INVALID; }
+  if (d->activation != PINN_ACT_TANH && d->activation != PINN_ACT_LEAKY_RELU) {
+    // mirrors the ValueError of dnn.py:23 for an unknown init_type
+    set_error("invalid activation %d (0 = tanh/'xavier', 1 = leaky_relu/'kaiming')", d->activation);
+    return PINN_ERR_INVALID;
+  }
+  n->d_in = d->d_in; n->d_out = d->d_out; n->L = d->n_hidden; n->W = d->width;
+  n->k = d->k; n->K1 = 1 + d->k; n->act = d->activation; n->n_lin = d->n_hidden + 1;
+  for (int j = 0; j < PINN_MAX_DIRS; ++j) {
+    n->dir_col[j] = j < d->k ? d->dir_col[j] : -1;
+    if (j < d->k && (d->dir_col[j] < 0 || d->dir_col[j] >= d->d_in)) {
+      set_error("dir_col[%d]=%d outside the %d input columns", j, d->dir_col[j], d->d_in);
+      return PINN_ERR_INVALID;
+    }
+  }
+  return PINN_OK;
+}
+
+static bool use_fused(const pinn_desc* d, const Net& n, int* rc) {
+  *rc = PINN_OK;
+  if (d->engine == PINN_ENGINE_GENERIC) return false;
+  const bool ok = fused_supports(n);
+  if (d->engine == PINN_ENGINE_FUSED && !ok) {
+    set_error("fused engine does not support this shape (width %d, d_in %d, d_out %d)", n.W, n.d_in, n.d_out);
+    *rc = PINN_ERR_UNSUPPORTED;
+  }
+  return ok;
+}
+
+static int residual_terms(int id) {
+  switch (id) {
+    case PINN_RES_NAVIER_STOKES: return PINN_NS_TERMS;
+    case PINN_RES_PHYSICS_EQUATION: return PINN_PE_TERMS;
+    case PINN_RES_CONTINUITY_FTEMP: return PINN_CF_TERMS;
+    case PINN_RES_CONTINUITY_ONLY: return PINN_CO_TERMS;
+  }
+  return -1;
+}
+
+static int check_spec(const Net& n, const pinn_residual_spec* sp) {
+  if (!sp) { set_error("spec is NULL"); return PINN_ERR_INVALID; }
+  int nr = 0, nd = 0;
+  switch (sp->residual_id) {
+    case PINN_RES_NAVIER_STOKES: nr = 4; nd = 3; break;
+    case PINN_RES_PHYSICS_EQUATION: nr = 6; nd = 2; break;
+    case PINN_RES_CONTINUITY_FTEMP:
+    case PINN_RES_CONTINUITY_ONLY: nr = 3; nd = 2; break;
+    default: set_error("unknown residual_id %d", sp->residual_id); return PINN_ERR_INVALID;
+  }
+  for (int r = 0; r < nr; ++r)
+    if (sp->out_col[r] < 0 || sp->out_col[r] >= n.d_out) {
+      set_error("out_col[%d]=%d outside the %d output columns", r, sp->out_col[r], n.d_out);
+      return PINN_ERR_INVALID;
+    }
+  for (int d = 0; d < nd; ++d)
+    if (sp->dir_of[d] < 0 || sp->dir_of[d] >= n.k) {
+      set_error("dir_of[%d]=%d but the network carries %d tangent directions", d, sp->dir_of[d], n.k);
+      return PINN_ERR_INVALID;
+    }
+  return PINN_OK;
+}
+
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                       float* __restrict__ v, int64_t P, float w1, float b2, float w2, float eps, float step_size,
+                       float bc2_sqrt) {
+  // torch.optim.Adam, _single_tensor_adam (the path train.py:192 takes on CPU):
+  //   exp_avg.lerp_(grad, 1-b1); exp_avg_sq.mul_(b2).addcmul_(grad, grad, value=1-b2)
+  //   denom = (exp_avg_sq.sqrt() / sqrt(bc2)).add_(eps); param.addcdiv_(exp_avg, denom, value=-lr/bc1)
+  // Scalars are formed in double on the host exactly as Python does, then cast to
+  // fp32 once; contraction is off so every op rounds where torch's rounds.
+#pragma clang fp contract(off)
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const float gi = g[i];
+  const float mi = m[i] + w1 * (gi - m[i]);
+  float vi = v[i] * b2;
+  vi = vi + (w2 * gi) * gi;
+  m[i] = mi; v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] = p[i] - step_size * (mi / denom);
+}
+
+}  // namespace pinn
+
+using namespace pinn;
+
+extern "C" {
+
+int32_t pinn_version(void) { return PINN_ABI_VERSION; }
+const char* pinn_last_error(void) { return g_err; }
+
+int32_t pinn_param_count(const pinn_desc* desc, int64_t* count) {
+  Net n; int rc = make_net(desc, &n); if (rc) return rc;
+  if (!count) { set_error("count is NULL"); return PINN_ERR_INVALID; }
+  *count = n.n_params();
+  return PINN_OK;
+}
+
+int32_t pinn_query_workspace(const pinn_desc* desc, int64_t N, int64_t* bytes) {
+  Net n; int rc = make_net(desc, &n); if (rc) return rc;
+  if (!bytes || N < 0) { set_error("bad arguments"); return PINN_ERR_INVALID; }
+  bool fused = use_fused(desc, n, &rc); if (rc) return rc;
+  // one workspace must serve every call on this network, including plain (k = 0) forwards
+  int64_t b = fused ? fused_workspace_bytes(n, N) : generic_workspace_bytes(n, N);
+  if (b < 0) { set_error("network not supported"); return PINN_ERR_UNSUPPORTED; }
+  *bytes = b;
+  return PINN_OK;
+}
+
+static int32_t forward_impl(const pinn_desc* desc, const float* params, const float* X, int64_t N, float* Y,
+                            float* dY, void* ws, int64_t ws_bytes, void* stream, bool jet) {
+  Net n; int rc = make_net(desc, &n); if (rc) return rc;
+  if (!params || !X || N < 0 || !Y || (jet && !dY)) { set_error("NULL pointer argument"); return PINN_ERR_INVALID; }
+  if (N == 0) return PINN_OK;
+  if (!jet) { n.k = 0; n.K1 = 1; dY = nullptr; }
+  if (jet && n.k == 0) { set_error("forward_jet needs k >= 1"); return PINN_ERR_INVALID; }
+  bool fused = use_fused(desc, n, &rc); if (rc) return rc;
+  return fused ? fused_forward(n, params, X, N, Y, dY, ws, ws_bytes, (hipStream_t)stream)
+               : generic_forward(n, params, X, N, Y, dY, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int32_t pinn_forward(const pinn_desc* desc, const float* params, const float* X, int64_t N, float* Y, void* ws,
+                     int64_t ws_bytes, void* stream) {
+  return forward_impl(desc, params, X, N, Y, nullptr, ws, ws_bytes, stream, false);
+}
+
+int32_t pinn_forward_jet(const pinn_desc* desc, const float* params, const float* X, int64_t N, float* Y,
+                         float* dY, void* ws, int64_t ws_bytes, void* stream) {
+  return forward_impl(desc, params, X, N, Y, dY, ws, ws_bytes, stream, true);
+}
+
+int32_t pinn_jet_backward(const pinn_desc* desc, const float* params, const float* X, int64_t N, const float* gY,
+                          const float* gdY, float* grad_flat, void* ws, int64_t ws_bytes, void* stream) {
+  Net n; int rc = make_net(desc, &n); if (rc) return rc;
+  if (!params || !X || N < 0 || !grad_flat || (!gY && !gdY)) { set_error("NULL pointer argument"); return PINN_ERR_INVALID; }
+  if (N == 0) return PINN_OK;
+  if (!gdY) { n.k = 0; n.K1 = 1; }
+  // generic consumer of the jet: the layer-wise engine handles every shape
+  return generic_jet_backward(n, params, X, N, gY, gdY, grad_flat, ws, ws_bytes, (hipStream_t)stream);
+}
+
+static int32_t residual_impl(const pinn_desc* desc, const pinn_residual_spec* spec, const float* term_scale,
+                             const float* params, const float* X, int64_t N, float* term_sums, float* grad_flat,
+                             void* ws, int64_t ws_bytes, void* stream, bool want_grad) {
+  Net n; int rc = make_net(desc, &n); if (rc) return rc;
+  rc = check_spec(n, spec); if (rc) return rc;
+  if (!params || !X || N < 0 || !term_sums || (want_grad && (!grad_flat || !term_scale))) {
+    set_error("NULL pointer argument"); return PINN_ERR_INVALID;
+  }
+  LossReq rq; memset(&rq, 0, sizeof(rq));
+  rq.kind = 0; rq.spec = *spec; rq.scale = term_scale; rq.sums = term_sums;
+  rq.grad = want_grad ? grad_flat : nullptr; rq.n_terms = residual_terms(spec->residual_id);
+  if (N == 0) { hipMemsetAsync(term_sums, 0, rq.n_terms * sizeof(float), (hipStream_t)stream); return PINN_OK; }
+  bool fused = use_fused(desc, n, &rc); if (rc) return rc;
+  return fused ? fused_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream)
+               : generic_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int32_t pinn_residual_loss(const pinn_desc* desc, const pinn_residual_spec* spec, const float* params,
+                           const float* X, int64_t N, float* term_sums, void* ws, int64_t ws_bytes, void* stream) {
+  return residual_impl(desc, spec, nullptr, params, X, N, term_sums, nullptr, ws, ws_bytes, stream, false);
+}
+
+int32_t pinn_residual_loss_grad(const pinn_desc* desc, const pinn_residual_spec* spec, const float* term_scale,
+                                const float* params, const float* X, int64_t N, float* term_sums,
+                                float* grad_flat, void* ws, int64_t ws_bytes, void* stream) {
+  return residual_impl(desc, spec, term_scale, params, X, N, term_sums, grad_flat, ws, ws_bytes, stream, true);
+}
+
+int32_t pinn_mse_loss_grad(const pinn_desc* desc, const float* params, const float* X, const float* T, int64_t N,
+                           int32_t n_cols, const int32_t* out_col, const float* col_scale, float* col_sums,
+                           float* grad_flat, void* ws, int64_t ws_bytes, void* stream) {
+  Net n; int rc = make_net(desc, &n); if (rc) return rc;
+  if (!params || !X || !T || N < 0 || !out_col || !col_sums || (grad_flat && !col_scale)) {
+    set_error("NULL pointer argument"); return PINN_ERR_INVALID;
+  }
+  if (n_cols < 1 || n_cols > PINN_MAX_ROLES) { set_error("n_cols=%d outside 1..%d", n_cols, PINN_MAX_ROLES); return PINN_ERR_INVALID; }
+  LossReq rq; memset(&rq, 0, sizeof(rq));
+  rq.kind = 1; rq.T = T; rq.n_cols = n_cols; rq.scale = col_scale; rq.sums = col_sums; rq.grad = grad_flat;
+  rq.n_terms = n_cols;
+  for (int j = 0; j < n_cols; ++j) {
+    if (out_col[j] < 0 || out_col[j] >= n.d_out) { set_error("out_col[%d]=%d out of range", j, out_col[j]); return PINN_ERR_INVALID; }
+    rq.out_col[j] = out_col[j];
+  }
+  if (N == 0) { hipMemsetAsync(col_sums, 0, n_cols * sizeof(float), (hipStream_t)stream); return PINN_OK; }
+  n.k = 0; n.K1 = 1;  // the fidelity term needs no input derivatives
+  bool fused = use_fused(desc, n, &rc); if (rc) return rc;
+  return fused ? fused_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream)
+               : generic_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int32_t pinn_adam_step(float* params, const float* grad, float* m, float* v, int64_t P, int64_t step, double lr,
+                       double beta1, double beta2, double eps, void* stream) {
+  if (!params || !grad || !m || !v || P < 0 || step < 1) { set_error("bad arguments"); return PINN_ERR_INVALID; }
+  if (P == 0) return PINN_OK;
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grad, m,
+                     v, P, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                     (float)(lr / bc1), (float)sqrt(bc2));
+  return check_launch("adam");
+}
+
+}  // extern "C"

@@ -1,0 +1,150 @@
+// residuals.h — per-point PDE residual fields and their adjoints, written on the
+// forward-mode jet (y, dy/dx_j) of the network outputs.
+//
+// The reference obtains every partial derivative with torch.autograd.grad
+// (physics.py:6-15) and the parameter gradient with a second reverse pass
+// (train.py:191).  All of its PDEs are first order in the inputs, so here the
+// residual is a pointwise function r(y, dy) of the jet and its adjoint
+// (dr/dy, dr/ddy) is written out by hand.  Each struct cites the lines it
+// restates.  v[c][r]: c = 0 value, c = 1+d the derivative along direction role
+// d; r = output role.  g has the same shape and receives
+// sum_t scale[t] * d(field_t^2)/dv.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pinn {
+
+// physics.py:50-88  Navier_Stokes(t, x, y, h, z, u, v)
+// roles: outputs h=0 z=1 u=2 v=3; directions t=0 x=1 y=2
+struct ResNavierStokes {
+  static constexpr int NR = 4, ND = 3, NT = 3;
+  template <bool GRAD>
+  __device__ static inline void eval(const float (&v)[1 + ND][NR], const float* scale,
+                                     float (&g)[1 + ND][NR], float (&sq)[NT]) {
+    const float h = v[0][0], z = v[0][1], u = v[0][2], w = v[0][3];
+    const float z_t = v[1][1], u_t = v[1][2], w_t = v[1][3];
+    const float h_x = v[2][0], z_x = v[2][1], u_x = v[2][2], w_x = v[2][3];
+    const float h_y = v[3][0], z_y = v[3][1], u_y = v[3][2], w_y = v[3][3];
+    const float G = 9.81f;                                      // physics.py:75
+    const float CB = (float)(3.0 / 16.0 * 9.81 * (0.78 * 0.78)); // physics.py:76-78
+    const float H = h + z;                  // total depth h+z (physics.py:64-68)
+    const float Hx = h_x + z_x, Hy = h_y + z_y;
+    const float hu_x = Hx * u + H * u_x;    // d((h+z)u)/dx  physics.py:67
+    const float hv_y = Hy * w + H * w_y;    // d((h+z)v)/dy  physics.py:68
+    const float Fbr_x = CB * Hx * H, Fbr_y = CB * Hy * H;       // physics.py:77-78
+    const float fc = z_t + hu_x + hv_y;                          // physics.py:81
+    const float fmx = u_t + u * u_x + w * u_y + G * z_x + Fbr_x; // physics.py:82
+    const float fmy = w_t + u * w_x + w * w_y + G * z_y + Fbr_y; // physics.py:83
+    sq[0] = fc * fc; sq[1] = fmx * fmx; sq[2] = fmy * fmy;       // physics.py:86
+    if (GRAD) {
+      const float rc = 2.f * scale[0] * fc, rx = 2.f * scale[1] * fmx, ry = 2.f * scale[2] * fmy;
+      const float gh = rc * (u_x + w_y) + CB * (rx * Hx + ry * Hy);
+      g[0][0] = gh; g[0][1] = gh;
+      g[0][2] = rc * Hx + rx * u_x + ry * w_x;
+      g[0][3] = rc * Hy + rx * u_y + ry * w_y;
+      g[1][0] = 0.f; g[1][1] = rc; g[1][2] = rx; g[1][3] = ry;
+      const float ghx = rc * u + rx * CB * H;
+      g[2][0] = ghx; g[2][1] = ghx + rx * G;
+      g[2][2] = rc * H + rx * u; g[2][3] = ry * u;
+      const float ghy = rc * w + ry * CB * H;
+      g[3][0] = ghy; g[3][1] = ghy + ry * G;
+      g[3][2] = rx * w; g[3][3] = rc * H + ry * w;
+    }
+  }
+};
+
+// physics.py:91-120  physics_equation(x, y, h, U, V, eta_mean, Hrms, k)
+// roles: outputs h=0 U=1 V=2 eta_mean=3 Hrms=4 k=5; directions x=0 y=1.
+// Bug-compatible with physics.py:106: E = 1/8**rho*g*Hrms**2 == 0.0, so the
+// radiation-stress terms Sxx_x, Syy_y contribute exactly 0 to loss and gradient
+// and Hrms, k receive zero adjoints.
+struct ResPhysicsEquation {
+  static constexpr int NR = 6, ND = 2, NT = 3;
+  template <bool GRAD>
+  __device__ static inline void eval(const float (&v)[1 + ND][NR], const float* scale,
+                                     float (&g)[1 + ND][NR], float (&sq)[NT]) {
+    const float h = v[0][0], U = v[0][1], V = v[0][2], eta = v[0][3];
+    const float U_x = v[1][1], V_x = v[1][2], e_x = v[1][3];
+    const float U_y = v[2][1], V_y = v[2][2], e_y = v[2][3];
+    const float G = 9.81f, RHO = 1025.f;
+    const float RC = (float)(1025 * 0.002);      // rho*Cd  physics.py:102-103
+    const float tbx = (RC * U) * fabsf(U);       // tau_bx  physics.py:102
+    const float tby = (RC * V) * fabsf(V);       // tau_by  physics.py:103
+    const float D = 1.0f / (RHO * (eta + h));    // physics.py:114-115
+    const float fc = U_x + V_y;                                  // physics.py:113
+    const float fx = U * U_x + V * U_y + G * e_x + D * tbx;      // physics.py:114 (Sxx_x+Sxy_y == 0)
+    const float fy = U * V_x + V * V_y + G * e_y + D * tby;      // physics.py:115
+    sq[0] = fc * fc; sq[1] = fx * fx; sq[2] = fy * fy;           // physics.py:118
+    if (GRAD) {
+      const float rc = 2.f * scale[0] * fc, rx = 2.f * scale[1] * fx, ry = 2.f * scale[2] * fy;
+#pragma unroll
+      for (int c = 0; c < 1 + ND; ++c)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) g[c][r] = 0.f;
+      const float dD = -RHO * D * D;             // d D / d(eta+h)
+      const float gS = dD * (rx * tbx + ry * tby);
+      g[0][0] = gS; g[0][3] = gS;
+      g[0][1] = rx * (U_x + D * RC * 2.f * fabsf(U)) + ry * V_x;
+      g[0][2] = rx * U_y + ry * (V_y + D * RC * 2.f * fabsf(V));
+      g[1][1] = rc + rx * U;   // d/dU_x
+      g[1][2] = ry * U;        // d/dV_x
+      g[1][3] = rx * G;        // d/deta_x
+      g[2][1] = rx * V;        // d/dU_y
+      g[2][2] = rc + ry * V;   // d/dV_y
+      g[2][3] = ry * G;        // d/deta_y
+    }
+  }
+};
+
+// physics.py:37-47 continuity_ftemp(x, y, h, U, V); physics.py:18-33 continuity_only
+// roles: outputs h=0 U=1 V=2; directions x=0 y=1.
+// fc = d(hU)/dx + d(hV)/dy.  continuity_only adds (h - anchor)^2 on the points
+// with x < threshold (physics.py:26-28); `masked` says whether this point is one.
+struct ResContinuity {
+  static constexpr int NR = 3, ND = 2, NT = 3;
+  template <bool GRAD>
+  __device__ static inline void eval(const float (&v)[1 + ND][NR], const float* scale,
+                                     float (&g)[1 + ND][NR], float (&sq)[NT],
+                                     bool anchor_on, bool masked, float anchor) {
+    const float h = v[0][0], U = v[0][1], V = v[0][2];
+    const float h_x = v[1][0], U_x = v[1][1];
+    const float h_y = v[2][0], V_y = v[2][2];
+    const float fc = h_x * U + h * U_x + h_y * V + h * V_y;      // physics.py:20-23,39-42
+    sq[0] = fc * fc;
+    const float da = (anchor_on && masked) ? (h - anchor) : 0.f; // physics.py:27-28
+    sq[1] = da * da;
+    sq[2] = (anchor_on && masked) ? 1.f : 0.f;
+    if (GRAD) {
+      const float rc = 2.f * scale[0] * fc;
+#pragma unroll
+      for (int c = 0; c < 1 + ND; ++c)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) g[c][r] = 0.f;
+      g[0][0] = rc * (U_x + V_y) + (anchor_on ? 2.f * scale[1] * da : 0.f);
+      g[0][1] = rc * h_x;
+      g[0][2] = rc * h_y;
+      g[1][0] = rc * U; g[1][1] = rc * h;
+      g[2][0] = rc * V; g[2][2] = rc * h;
+    }
+  }
+};
+
+// ---- activations (dnn.py:18-21) ------------------------------------------------
+// tanh: odd minimax polynomial below 0.625 (relative error ~1e-7), the
+// exponential form above; abs error <= ~1.5e-7 everywhere in fp32.
+__device__ inline float tanh_f32(float x) {
+  const float ax = fabsf(x);
+  const float x2 = x * x;
+  float p = -5.70498872745e-3f;
+  p = fmaf(p, x2, 2.06390887954e-2f);
+  p = fmaf(p, x2, -5.37397155531e-2f);
+  p = fmaf(p, x2, 1.33314422036e-1f);
+  p = fmaf(p, x2, -3.33332819422e-1f);
+  const float small = fmaf(p * x2, x, x);
+  // 1 - 2/(exp(2|x|)+1); exp2 argument clamps naturally (inf -> 1)
+  const float e = __expf(2.f * ax);
+  const float big = copysignf(1.f - 2.f * __frcp_rn(e + 1.f), x);
+  return ax < 0.625f ? small : big;
+}
+
+}  // namespace pinn
