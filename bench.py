@@ -1,0 +1,159 @@
+#!/usr/bin/env python
+"""bench.py — collocation-point residuals/sec for one full optimisation step
+(forward + PDE partials + d loss/d theta + Adam) on BASELINE.json configs[1]:
+3 -> 8x64 tanh -> 4, Navier_Stokes residual, 2^20 synthetic (t,x,y) points per GPU, fp32.
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is the arithmetic of train.py:189-193 (zero_grad, loss_func, backward,
+Adam.step, StepLR.step) on the full batch, with per-iteration logging off.
+Points are sharded across ranks (weak scaling: 2^20 per GPU); one RCCL all-reduce of
+[grad | loss sums] per step.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+FLOP_PER_POINT = 695_424          # 6*M*(1+k), M = 29 120, k = 3 (3->8x64->4)
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PTS_PER_GPU = 1 << 20
+
+
+def cpu_baseline(threads: int):
+    """Oracle (autograd formulation of the reference, torch CPU) timed on a bounded sample:
+    N = 10 000 points (BASELINE configs[0] size), 3 warm-ups + steps until ~12 s."""
+    from oracle import pinn_oracle as O
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(1234)
+    layers = O.layer_sizes(3, 8, 64, 4)
+    params = [p.requires_grad_(True) for p in O.init_params(layers, "xavier", g)]
+    N = 10_000
+    X = torch.rand(N, 3, generator=g) * 2 - 1
+    opt = torch.optim.Adam(params, lr=1e-4)
+
+    def step():
+        opt.zero_grad()
+        loss = O.residual_loss(params, X, "Navier_Stokes", [0, 1, 2], [0, 1, 2, 3], (0, 1, 2))
+        loss.backward()
+        opt.step()
+
+    for _ in range(3):
+        step()
+    t0, n = time.perf_counter(), 0
+    while n < 5 or time.perf_counter() - t0 < 12.0:
+        step(); n += 1
+        if n >= 200:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": N * n / dt, "unit": "residual-points/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/pinn_oracle.py (13x autograd.grad + double backward + torch Adam), "
+                      f"N={N} points x {n} steps, 3->8x64->4 Navier_Stokes, fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=PTS_PER_GPU, help="points per GPU")
+    ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 generic, 2 fused")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    from pinn_depthestimation_amd import Engine, NetDesc, ResidualSpec
+    from pinn_depthestimation_amd.dnn import init_flat_params
+
+    desc = NetDesc(3, 4, 8, 64, (0, 1, 2), engine=args.engine)
+    spec = ResidualSpec.from_names("Navier_Stokes", ("t", "x", "y"), desc.grad_cols, ("h", "z", "u", "v"))
+    eng = Engine(desc, dev)
+    P = desc.n_params
+    g = torch.Generator().manual_seed(1234)              # same weights on every rank
+    params = init_flat_params(desc.layers, "xavier", g).to(dev)
+    gx = torch.Generator().manual_seed(1234 + 7919 * rank)  # each rank its own shard of points
+    N = args.points
+    X = (torch.rand(N, 3, generator=gx) * 2 - 1).to(dev)
+    n_global = N * world
+    scale = torch.full((3,), 1.0 / n_global, device=dev)
+    buf = torch.zeros(P + 3, device=dev)                  # [grad | term sums]: ONE all-reduce per step
+    grad, sums = buf[:P], buf[P:]
+    m, v = torch.zeros(P, device=dev), torch.zeros(P, device=dev)
+    lr0, gamma, sched_step = 1e-4, 0.8, 10000            # config_CMB.json:11-16
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+
+    def step(i, timed_idx=None):
+        grad.zero_()
+        if timed_idx is not None: ev[timed_idx][0].record()
+        eng.residual_loss_grad(spec, scale, params, X, grad, sums=sums)
+        if timed_idx is not None: ev[timed_idx][1].record()
+        if world > 1:
+            dist.all_reduce(buf)
+        lr = lr0 * gamma ** (i // sched_step)
+        eng.adam_step(params, grad, m, v, i + 1, lr)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, i)
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t)
+    loss = float((sums * scale).sum())
+
+    if rank == 0:
+        kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+        achieved = N * FLOP_PER_POINT / (kern_ms * 1e-3) / 1e12
+        out = {
+            "metric": "collocation-point residuals/sec (fwd+PDE-grad+Adam)",
+            "value": n_global * args.steps / dt, "unit": "residual-points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 3->8x64 tanh->4 MLP, Navier_Stokes residual, "
+                                   f"{N} synthetic (t,x,y) points per GPU, full-batch Adam step",
+                       "points_per_gpu": N, "global_points": n_global, "params": P,
+                       "parallelism": f"dp{world}", "engine": args.engine, "final_loss": loss},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "pinn_residual_loss_grad (fwd jet + residual + reverse sweep)",
+                         "kernel_ms": kern_ms, "flop_per_point": FLOP_PER_POINT},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,118 @@
+"""Pins oracle/pinn_oracle.py to vectors captured from the reference's own dnn.py/physics.py
+(tests/golden/make_goldens.py).  CPU only.  Same formulation, same torch build => the fp32
+results agree to rounding; tolerances below are ~10x the observed differences."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pinn_oracle as O
+from tests.golden_util import layers_of, load, rel_l2, state_dict
+
+torch.set_num_threads(8)
+
+
+def test_g1_forward_g2_jet_g3_navier_stokes():
+    z = load("g1_g3_ns_8x64.npz")
+    sd = state_dict(z)
+    params = O.params_from_state_dict(sd)
+    assert layers_of(sd) == [3] + [64] * 8 + [4]
+    X = torch.from_numpy(z["X"])
+    Y = O.mlp_forward(params, X)
+    assert torch.allclose(Y, torch.from_numpy(z["Y"]), rtol=0, atol=1e-7)
+    Yj, dY = O.jet(params, X, (0, 1, 2))
+    assert np.abs(dY.numpy() - z["dY"]).max() < 1e-6
+    p = [q.clone().requires_grad_(True) for q in params]
+    loss = O.residual_loss(p, X, "Navier_Stokes", [0, 1, 2], [0, 1, 2, 3], (0, 1, 2))
+    assert abs(float(loss) - float(z["loss"])) / float(z["loss"]) < 1e-6
+    assert rel_l2(O.flat_grad(loss, p), z["grad"]) < 1e-6
+
+
+@pytest.mark.parametrize("name,tol_l,tol_g", [("g4_pe_8x64_conditioned.npz", 1e-6, 1e-5),
+                                               ("g4_pe_10x10_rawinit.npz", 1e-5, 1e-4)])
+def test_g4_physics_equation(name, tol_l, tol_g):
+    z = load(name)
+    params = O.params_from_state_dict(state_dict(z))
+    X = torch.from_numpy(z["X"])
+    assert torch.allclose(O.mlp_forward(params, X), torch.from_numpy(z["Y"]), rtol=0, atol=1e-7)
+    for dt, tag in ((torch.float32, ""), (torch.float64, "64")):
+        p = [q.to(dt).requires_grad_(True) for q in params]
+        loss = O.residual_loss(p, X.to(dt), "physics_equation", [0, 1], [0, 1, 2, 3, 4, 5], (0, 1))
+        assert abs(float(loss) - float(z["loss" + tag])) / float(z["loss" + tag]) < tol_l
+        assert rel_l2(O.flat_grad(loss, p), z["grad" + tag]) < tol_g
+
+
+def test_g4_radiation_stress_is_exactly_zero():
+    """physics.py:106 — E = 1/8**rho*g*Hrms**2 is 0.0, so Hrms and k get zero gradient."""
+    z = load("g4_pe_8x64_conditioned.npz")
+    sd = state_dict(z)
+    g = torch.from_numpy(z["grad"])
+    params = O.params_from_state_dict(sd)
+    gl = O.unflatten(g, layers_of(sd))
+    assert 1 / 8 ** 1025 == 0.0
+    assert torch.count_nonzero(gl[-2][4:6]) == 0 and torch.count_nonzero(gl[-1][4:6]) == 0
+    assert torch.count_nonzero(gl[-2][0:4]) > 0
+
+
+def test_g5_continuity():
+    z = load("g5_continuity_4x20.npz")
+    params = O.params_from_state_dict(state_dict(z))
+    X = torch.from_numpy(z["X"])
+    assert int(z["count"]) == int((X[:, 0] < 25.5).sum()) and 0 < int(z["count"]) < X.shape[0]
+    for fn in ("continuity_only", "continuity_ftemp"):
+        p = [q.clone().requires_grad_(True) for q in params]
+        # outputs ordered (U, V, h) as train_newmethod.py:136-139; residual args are (x, y, h, U, V)
+        loss = O.residual_loss(p, X, fn, [0, 1], [2, 0, 1], (0, 1))
+        assert abs(float(loss) - float(z[fn + "/loss"])) / float(z[fn + "/loss"]) < 1e-6
+        assert rel_l2(O.flat_grad(loss, p), z[fn + "/grad"]) < 1e-6
+
+
+def test_g6_loss_func_config_cmb():
+    z = load("g6_lossfunc_cmb.npz")
+    params = O.params_from_state_dict(state_dict(z))
+    p = [q.clone().requires_grad_(True) for q in params]
+    fid = O.fidelity_loss(p, torch.from_numpy(z["Xf"]), torch.from_numpy(z["Tf"]), range(6), [1] * 6)
+    res = O.residual_loss(p, torch.from_numpy(z["Xr"]), "physics_equation", [0, 1], [0, 1, 2, 3, 4, 5], (0, 1))
+    loss = 1 * fid + 1 * res
+    assert abs(float(fid) - float(z["fid"])) / float(z["fid"]) < 1e-6
+    assert abs(float(res) - float(z["res"])) / float(z["res"]) < 1e-5
+    assert rel_l2(O.flat_grad(loss, p), z["grad"]) < 1e-5
+
+
+def test_g7_adam_trajectory_prefix():
+    z0, z = load("g1_g3_ns_8x64.npz"), load("g7_adam_ns_8x64.npz")
+    params = O.params_from_state_dict(state_dict(z0))
+    X = torch.from_numpy(z["X"])
+    n = 12
+    losses, _ = O.adam_trajectory(
+        params, lambda p: O.residual_loss(p, X, "Navier_Stokes", [0, 1, 2], [0, 1, 2, 3], (0, 1, 2)),
+        steps=n, lr=1e-4, step_size=50, gamma=0.8)
+    ref = z["losses"][:n]
+    assert np.max(np.abs(np.array(losses) - ref) / ref) < 1e-5
+
+
+def test_g8_lbfgs_trajectory():
+    z7, z = load("g7_adam_ns_8x64.npz"), load("g8_lbfgs_ns_8x64.npz")
+    params = O.params_from_state_dict(state_dict(z7, "sd_end/"))
+    X = torch.from_numpy(z7["X"][:2000])
+    losses, _ = O.lbfgs_trajectory(
+        params, lambda p: O.residual_loss(p, X, "Navier_Stokes", [0, 1, 2], [0, 1, 2, 3], (0, 1, 2)), max_iter=50)
+    ref = z["losses"]
+    # the first evaluation is rounding-exact; later ones go through a branchy line search
+    assert abs(losses[0] - ref[0]) / ref[0] < 1e-6
+    assert abs(len(losses) - len(ref)) <= 3
+    assert abs(losses[-1] - ref[-1]) / ref[-1] < 5e-2
+
+
+def test_g9_newmethod_first_step():
+    z = load("g9_newmethod_at50k.npz")
+    X, U, V = (torch.from_numpy(z[k]) for k in ("X", "U", "V"))
+    assert X.shape == (12514, 2) and U.shape == (12514, 1)     # data_at50k.mat column sizes
+    for tag in ("8x64",):
+        params = O.params_from_state_dict(state_dict(z, f"{tag}/sd/"))
+        p = [q.clone().requires_grad_(True) for q in params]
+        T = torch.cat([U, V], 1)
+        fid = O.fidelity_loss(p, X, T, [0, 1], [1.0, 1.0])   # F.mse_loss per column, train_newmethod.py:129-133
+        res = O.residual_loss(p, X, "continuity_only", [0, 1], [2, 0, 1], (0, 1))
+        assert abs(float(fid) - float(z[f"{tag}/fid0"])) / float(z[f"{tag}/fid0"]) < 1e-6
+        assert abs(float(res) - float(z[f"{tag}/res0"])) / float(z[f"{tag}/res0"]) < 1e-5
+        assert rel_l2(O.flat_grad(fid + res, p), z[f"{tag}/grad0"]) < 1e-5
