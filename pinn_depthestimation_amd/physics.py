@@ -1,0 +1,84 @@
+"""physics — drop-in for the reference's physics.py: same function names, argument order and
+return value (a 0-dim loss tensor that supports .backward() and .item()).
+
+Each residual first tries the FUSED path: if its arguments are the input columns and the
+output columns of one DNN.forward call (what train.py:144-154 / train_newmethod.py:122-156
+pass), the whole loss and d loss / d theta come from one pinn_residual_loss_grad kernel.
+Otherwise it evaluates the same formulas through compute_gradient, whose derivatives come
+from the forward-mode jet (autograd.py) — still the HIP engine, never a CPU path.
+"""
+from __future__ import annotations
+
+import torch
+
+from .autograd import fused_residual
+
+
+def compute_gradient(pred, var):
+    """d pred / d var per collocation point, differentiable w.r.t. the network parameters
+    (reference physics.py:6-15)."""
+    (grad,) = torch.autograd.grad(pred, var, grad_outputs=torch.ones_like(pred),
+                                  retain_graph=True, create_graph=True)
+    return grad
+
+
+def _mean_sq(*fields):
+    total = 0
+    for f in fields:
+        total = total + torch.mean(f ** 2)
+    return total
+
+
+def _continuity_field(x, y, h, U, V):
+    # mass flux divergence d(hU)/dx + d(hV)/dy  (physics.py:20-23, 39-42)
+    return compute_gradient(h * U, x) + compute_gradient(h * V, y)
+
+
+def continuity_only(x, y, h, U, V):
+    """physics.py:18-33 — continuity plus the depth anchor h = 0.75 where x < 25.5."""
+    fused = fused_residual("continuity_only", (x, y), (h, U, V))
+    if fused is not None:
+        return fused
+    fc = _continuity_field(x, y, h, U, V)
+    sel = torch.where(x < 25.5)
+    return torch.mean(fc ** 2) + torch.mean((h[sel] - 0.75) ** 2)
+
+
+def continuity_ftemp(x, y, h, U, V):
+    """physics.py:37-47"""
+    fused = fused_residual("continuity_ftemp", (x, y), (h, U, V))
+    if fused is not None:
+        return fused
+    return _mean_sq(_continuity_field(x, y, h, U, V))
+
+
+def Navier_Stokes(t, x, y, h, z, u, v):
+    """physics.py:50-88 — unsteady shallow-water continuity + x/y momentum with the
+    wave-breaking force 3/16 g gamma_b^2 d(h+z)/dx (h+z); friction terms are zero."""
+    fused = fused_residual("Navier_Stokes", (t, x, y), (h, z, u, v))
+    if fused is not None:
+        return fused
+    d = compute_gradient
+    depth = h + z
+    g, gamma_b = 9.81, 0.78
+    cb = 3.0 / 16.0 * g * gamma_b ** 2
+    mass = d(z, t) + d(depth * u, x) + d(depth * v, y)
+    mom_x = d(u, t) + u * d(u, x) + v * d(u, y) + g * d(z, x) + cb * d(depth, x) * depth
+    mom_y = d(v, t) + u * d(v, x) + v * d(v, y) + g * d(z, y) + cb * d(depth, y) * depth
+    return _mean_sq(mass, mom_x, mom_y)
+
+
+def physics_equation(x, y, h, U, V, eta_mean, Hrms, k):
+    """physics.py:91-120 — steady wave-averaged continuity + momentum with quadratic bottom
+    friction.  Bug-compatible: the reference's E = 1/8**rho*g*Hrms**2 (physics.py:106) is
+    exactly 0.0, so the radiation-stress gradients vanish and Hrms, k do not enter."""
+    fused = fused_residual("physics_equation", (x, y), (h, U, V, eta_mean, Hrms, k))
+    if fused is not None:
+        return fused
+    d = compute_gradient
+    g, rho, cd = 9.81, 1025, 0.002
+    inv_depth = 1 / (rho * (eta_mean + h))
+    mass = d(U, x) + d(V, y)
+    mom_x = U * d(U, x) + V * d(U, y) + g * d(eta_mean, x) + inv_depth * (rho * cd * U * abs(U))
+    mom_y = U * d(V, x) + V * d(V, y) + g * d(eta_mean, y) + inv_depth * (rho * cd * V * abs(V))
+    return _mean_sq(mass, mom_x, mom_y)

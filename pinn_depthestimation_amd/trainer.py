@@ -1,0 +1,220 @@
+"""trainer — the `pinn` training harness of train.py:46-200 / train_newmethod.py:46-209 on the
+HIP engine: same constructor arguments, same loss arithmetic, same Adam+StepLR then one
+LBFGS.step(closure) schedule, same log.txt / model_{iter}.pth artefacts.
+
+One closure evaluation =
+    grad <- 0
+    fidelity   : pinn_mse_loss_grad       (train.py:131-141)
+    residual   : pinn_residual_loss_grad  (train.py:144-154 + loss.backward(), :191)
+    all-reduce : [grad | loss sums] over the data-parallel group (parallel.py)
+No host synchronisation happens unless a log line is due (`log_every`; the reference logs
+every call, train.py:160-173 — pass log_every=1 for that).
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from ._lib import PinnError
+from .config import PinnConfig, load_config
+from .dnn import DNN
+from .engine import ACTIVATION_OF_INIT, Engine, NetDesc, ResidualSpec
+from .parallel import Reducer
+
+
+def _as_f32(a, device) -> Optional[torch.Tensor]:
+    if a is None:
+        return None
+    t = torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a)
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class HipEvaluator:
+    """Local-shard loss sums and gradient through libpinn_hip.so."""
+
+    def __init__(self, cfg_layers, init_type, grad_cols, spec: ResidualSpec, fid_cols: Sequence[int], device,
+                 engine: int = 0):
+        act = ACTIVATION_OF_INIT[init_type]
+        self.eng = Engine(NetDesc.from_layers(cfg_layers, grad_cols, act, engine), device)
+        self.spec, self.fid_cols = spec, list(fid_cols)
+
+    def __call__(self, theta, Xf, Tf, fid_scale, Xr, res_scale, grad, fid_sums, res_sums):
+        if Xf is not None and Xf.shape[0] > 0:
+            self.eng.mse_loss_grad(theta, Xf, Tf, self.fid_cols, fid_scale, grad, sums=fid_sums)
+        else:
+            fid_sums.zero_()
+        if Xr is not None and Xr.shape[0] > 0:
+            self.eng.residual_loss_grad(self.spec, res_scale, theta, Xr, grad, sums=res_sums)
+        else:
+            res_sums.zero_()
+
+
+class PINN:
+    """The physics-guided network harness (reference `class pinn`, train.py:46)."""
+
+    def __init__(self, fidelity_input, fidelity_true, residual_input, config, residual: Optional[str] = None,
+                 device="cuda", log_dir: Optional[str] = None, log_every: int = 1, checkpoint_every: int = 1000,
+                 reducer: Optional[Reducer] = None, evaluator: Optional[Callable] = None,
+                 dnn: Optional[DNN] = None, engine: int = 0):
+        cfg = config if isinstance(config, PinnConfig) else load_config(config)
+        self.config, self.device = cfg, torch.device(device)
+        self.reducer = reducer or Reducer()
+        self.layers = cfg.layers                                           # train.py:52-56
+        self.dnn = dnn if dnn is not None else DNN(cfg.layers, cfg.dropout_rate, cfg.init_type)
+        self.dnn.to(self.device)
+        self.theta = self.dnn.flat_params()
+        self.reducer.broadcast_(self.theta)                                # replicas start identical
+        P = self.theta.numel()
+
+        residual = residual or cfg.default_residual()
+        self.spec = ResidualSpec.from_names(residual, cfg.residual_inputs, cfg.grad_cols, cfg.residual_outputs)
+        # i-th fidelity output is compared with output column i (train.py:137-138, train_newmethod.py:129-131)
+        self.fid_cols = list(range(len(cfg.fidelity_outputs)))
+        if cfg.variant == "newmethod":
+            fid_w = [1.0] * len(self.fid_cols)                             # F.mse_loss, unweighted sum
+        else:
+            fid_w = [cfg.output_weight(k) for k in cfg.fidelity_outputs]   # train.py:94-95,140
+        self.weight_fidelity, self.weight_residual = cfg.weight_fid, cfg.weight_res
+
+        Xf, Tf, Xr = (_as_f32(a, self.device) for a in (fidelity_input, fidelity_true, residual_input))
+        self.n_fid = 0 if Xf is None else Xf.shape[0]
+        self.n_res = 0 if Xr is None else Xr.shape[0]
+        self.Xf, self.Tf, self.Xr = self.reducer.shard(Xf), self.reducer.shard(Tf), self.reducer.shard(Xr)
+        nf, nt = len(self.fid_cols), self.spec.n_terms
+        dev = self.device
+        self._fid_unit = torch.tensor(fid_w, dtype=torch.float32, device=dev) / max(self.n_fid, 1)
+        if residual == "continuity_only":
+            xcol = cfg.grad_cols[self.spec.dir_of[0]]
+            cnt = (self.Xr[:, xcol] < self.spec.threshold).sum().to(torch.float32).reshape(1)
+            self.reducer.allreduce_sum_(cnt)                               # global count of x < 25.5
+            self._res_unit = torch.cat([torch.tensor([1.0 / self.n_res], device=dev), 1.0 / cnt,
+                                        torch.zeros(1, device=dev)])
+        else:
+            self._res_unit = torch.full((nt,), 1.0 / max(self.n_res, 1), dtype=torch.float32, device=dev)
+        self._fid_scale = (self.weight_fidelity * self._fid_unit).contiguous()
+        self._res_scale = (self.weight_residual * self._res_unit).contiguous()
+        self.buf = torch.zeros(P + nf + nt, dtype=torch.float32, device=dev)   # ONE all-reduce per closure
+        self.grad = self.buf[:P]
+        self._fid_sums, self._res_sums = self.buf[P:P + nf], self.buf[P + nf:]
+        self.evaluator = evaluator or HipEvaluator(cfg.layers, cfg.init_type, cfg.grad_cols, self.spec,
+                                                   self.fid_cols, dev, engine)
+
+        self.iter = 0                                                      # train.py:73
+        self.adam_maxit = cfg.adam["max_it"]
+        self.log_dir, self.log_every, self.checkpoint_every = log_dir, max(int(log_every), 1), checkpoint_every
+        self._log_fh = None
+        self.history: List[tuple] = []
+        self.last = None
+        self.init_optimizers()
+
+    # ---- optimisers (train.py:100-125) ----------------------------------------------------------
+    def init_optimizers(self):
+        a, lb = self.config.adam, self.config.lbfgs
+        self._adam_m = torch.zeros_like(self.theta)
+        self._adam_v = torch.zeros_like(self.theta)
+        self._adam_step = 0
+        self._sched_steps = 0
+        self.theta_param = torch.nn.Parameter(self.theta)       # shares storage with every Linear weight
+        self.optimizer_LBFGS = torch.optim.LBFGS(
+            [self.theta_param], lr=lb["learning_rate"], max_iter=lb["max_it"], max_eval=lb.get("max_evaluation"),
+            history_size=lb["history_size"], tolerance_grad=lb["tolerance_grad"],
+            tolerance_change=lb["tolerance_change"], line_search_fn=lb["line_search_fn"])
+
+    def current_lr(self) -> float:
+        """StepLR(step_size, gamma) stepped once per Adam iteration (train.py:109-113,193)."""
+        a = self.config.adam
+        return a["learning_rate"] * a["scheduler_gamma"] ** (self._sched_steps // a["scheduler_step_size"])
+
+    # ---- loss (train.py:128-181) ----------------------------------------------------------------------
+    def loss_func(self) -> torch.Tensor:
+        """Total loss (0-dim device tensor); self.grad holds d loss / d theta afterwards."""
+        self.theta = self.dnn.flat_params()
+        self.buf.zero_()
+        self.evaluator(self.theta, self.Xf, self.Tf, self._fid_scale, self.Xr, self._res_scale, self.grad,
+                       self._fid_sums, self._res_sums)
+        self.reducer.allreduce_sum_(self.buf)
+        fidelity_loss = (self._fid_sums * self._fid_unit).sum()
+        residual_loss = (self._res_sums * self._res_unit).sum()
+        loss = self.weight_fidelity * fidelity_loss + self.weight_residual * residual_loss   # train.py:157
+        self.last = (fidelity_loss, residual_loss, loss)
+        self.iter += 1                                                                        # train.py:160
+        if self.iter % self.log_every == 0 or self.iter % 1000 == 0:
+            self._log(fidelity_loss.item(), residual_loss.item(), loss.item())
+        if self.checkpoint_every and self.iter % self.checkpoint_every == 0:
+            self.save_checkpoint(f"model_{self.iter}.pth")                                    # train.py:175-179
+        return loss
+
+    def _log(self, fid: float, res: float, tot: float):
+        self.history.append((self.iter, fid, res, tot))
+        if self.iter % 1000 == 0 and self.reducer.rank == 0:
+            print(f"Epoch {self.iter}, Fidelity Loss: {fid:.5e}, Residual Loss: {res:.5e}, Total Loss: {tot:.5e}")
+        if self.log_dir is None or self.reducer.rank != 0:
+            return
+        if self._log_fh is None:
+            os.makedirs(self.log_dir, exist_ok=True)
+            path = os.path.join(self.log_dir, "log.txt")
+            new = not os.path.exists(path) or os.stat(path).st_size == 0
+            self._log_fh = open(path, "a")
+            if new:
+                self._log_fh.write("Epoch, Fidelity Loss, Residual Loss, Total Loss\n")       # train.py:167
+        self._log_fh.write(f"{self.iter}, {fid:.5e}, {res:.5e}, {tot:.5e}\n")                 # train.py:170
+        self._log_fh.flush()
+
+    def save_checkpoint(self, name: str):
+        if self.log_dir is None or self.reducer.rank != 0:
+            return
+        os.makedirs(self.log_dir, exist_ok=True)
+        torch.save(self.dnn, os.path.join(self.log_dir, name))                    # whole module, as train.py:179
+        torch.save(self.dnn.state_dict(), os.path.join(self.log_dir, name.replace(".pth", ".state.pth")))
+
+    # ---- training (train.py:185-200) ------------------------------------------------------------------
+    def adam_step(self):
+        """zero_grad / loss_func / backward / Adam.step / StepLR.step (train.py:189-193)."""
+        loss = self.loss_func()
+        self._adam_step += 1
+        eng = getattr(self.evaluator, "eng", None)
+        lr = self.current_lr()
+        if eng is not None:
+            eng.adam_step(self.theta, self.grad, self._adam_m, self._adam_v, self._adam_step, lr)
+        else:   # injected evaluator (CPU tests): same arithmetic in torch
+            _torch_adam(self.theta, self.grad, self._adam_m, self._adam_v, self._adam_step, lr)
+        self._sched_steps += 1
+        return loss
+
+    def closure(self):
+        """train.py:195-199"""
+        loss = self.loss_func()
+        self.theta_param.grad = self.grad.clone()
+        return loss
+
+    def train(self):
+        self.dnn.train()
+        for _ in range(self.adam_maxit):
+            self.adam_step()
+        if self.config.lbfgs["max_it"] > 0:
+            self.optimizer_LBFGS.step(self.closure)                                # ONE step, train.py:200
+        if self._log_fh is not None:
+            self._log_fh.flush()
+
+    def predict(self, inputs) -> torch.Tensor:
+        """Forward on a grid (test.py:76): (N, d_in) -> (N, d_out)."""
+        X = _as_f32(inputs, self.device)
+        eng = getattr(self.evaluator, "eng", None)
+        if eng is None:
+            raise PinnError("predict needs the HIP evaluator")
+        return eng.forward(self.dnn.flat_params(), X)
+
+
+def _torch_adam(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.Adam's single-tensor update, used only with an injected evaluator."""
+    m.lerp_(g, 1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    denom = (v.sqrt() / (bc2 ** 0.5)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+pinn = PINN   # the reference's class name (train.py:46)
