@@ -27,11 +27,35 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PTS_PER_GPU = 1 << 20
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cpus() -> int:
+    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota
+    (os.cpu_count() reports the whole host and oversubscribes a container)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, min(n, 32))
+
+
 def cpu_baseline(threads: int):
     """Oracle (autograd formulation of the reference, torch CPU) timed on a bounded sample:
-    N = 10 000 points (BASELINE configs[0] size), 3 warm-ups + steps until ~12 s."""
+    N = 10 000 points (BASELINE configs[0] size), 1 warm-up + steps until ~12 s."""
     from oracle import pinn_oracle as O
     torch.set_num_threads(threads)
+    log(f"cpu baseline on {threads} threads")
     g = torch.Generator().manual_seed(1234)
     layers = O.layer_sizes(3, 8, 64, 4)
     params = [p.requires_grad_(True) for p in O.init_params(layers, "xavier", g)]
@@ -45,14 +69,12 @@ def cpu_baseline(threads: int):
         loss.backward()
         opt.step()
 
-    for _ in range(3):
-        step()
+    step()
     t0, n = time.perf_counter(), 0
-    while n < 5 or time.perf_counter() - t0 < 12.0:
+    while n < 1 or (time.perf_counter() - t0 < 12.0 and n < 200):
         step(); n += 1
-        if n >= 200:
-            break
     dt = time.perf_counter() - t0
+    log(f"cpu baseline: {n} steps in {dt:.1f} s")
     return {"value": N * n / dt, "unit": "residual-points/s", "cores": threads, "kind": "port",
             "sample": f"oracle/pinn_oracle.py (13x autograd.grad + double backward + torch Adam), "
                       f"N={N} points x {n} steps, 3->8x64->4 Navier_Stokes, fp32"}
@@ -116,9 +138,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log(f"rank {rank}/{world}: {N} points, P={P}, engine={args.engine}; warm-up")
     for i in range(args.warmup):
         step(i)
     barrier()
+    log("timing")
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i, i)
@@ -129,6 +153,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t)
     loss = float((sums * scale).sum())
+    log(f"{args.steps} steps in {dt:.3f} s; loss {loss:.5e}")
 
     if rank == 0:
         kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
@@ -149,7 +174,7 @@ def main():
                          "kernel_ms": kern_ms, "flop_per_point": FLOP_PER_POINT},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(usable_cpus())
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
