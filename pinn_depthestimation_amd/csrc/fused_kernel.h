@@ -1,0 +1,462 @@
+// fused_kernel.h — the MI355X fast path: one persistent kernel that, per tile of 16
+// collocation points and per wave, runs
+//     forward-mode jet through every layer  (dnn.py:54-55 + physics.py:6-15)
+//  -> PDE residual + its adjoint             (physics.py:18-120, train.py:131-157)
+//  -> reverse sweep: d loss / d theta        (train.py:191)
+// entirely on v_mfma_f32_16x16x4_f32 (exact fp32, fmaf-chain numerics).
+//
+// Layout ("acc layout"): a 16(feature) x 16(point) tile lives in one f4 per lane;
+// lane = (p = lane&15 point, q = lane>>4), register r  <->  feature 4q + r, point p.
+// That is the C/D layout of the 16x16x4 MFMA, and — with the K index permuted so that
+// k-step (tile kt, reg r) carries features {16kt + 4q + r : q = 0..3} — it is ALSO its B
+// operand layout: a layer's accumulators feed the next layer's MFMAs with no data
+// movement.  The matching A operand (weights) is then W[16MT + m][16kt + 4kq + r],
+// r = 0..3 contiguous: one 16-byte load from the row-major (padded) weights.  The
+// reverse sweep uses the same chain on W^T.  Only the weight-gradient GEMM
+// (dW = Zbar . A^T, contraction over points) needs points on the K axis: each
+// 16x16 block is transposed through a wave-private 1.25 KB LDS pad.
+//
+// Activations needed by the reverse sweep are spilled to a per-wave global scratch
+// slot in fragment-native order (fully coalesced 16 B/lane both ways; written once,
+// read twice, L2/MALL resident).  dW/db are accumulated with LDS float atomics in a
+// per-workgroup copy of the (padded) gradient, written out once per workgroup and
+// summed across workgroups by a second kernel in a fixed order.
+#pragma once
+#include <string.h>
+#include <type_traits>
+#include "common.h"
+#include "residuals.h"
+
+namespace pinn {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int FUSED_WAVES = 8;
+constexpr int FUSED_THREADS = FUSED_WAVES * 64;
+constexpr int TB_STRIDE = 20;                 // floats per row of a transpose block (80 B: conflict-free b128 writes)
+constexpr int TB_FLOATS = 16 * TB_STRIDE;     // one 16x16 block
+constexpr int TB_PER_WAVE = 2;
+constexpr int MAX_SUMS = 8;
+
+struct FusedParams {
+  int d_in, d_out, L, act;
+  int dir_col[PINN_MAX_DIRS];
+  int64_t N, n_tiles;
+  const float* X;
+  const float* Wp;    // padded weights, row-major [out][in] per layer
+  const float* WTp;   // padded transposed weights, row-major [in][out] per layer
+  const float* Bp;    // padded biases
+  float* scratch;     // activation spill, scratch_per_wave floats per wave
+  int64_t scratch_per_wave;
+  float* Y; float* dY;  // forward outputs (may be null)
+  int loss_kind;        // 0 none, 1 residual, 2 mse
+  int residual_id;
+  int out_col[PINN_MAX_ROLES];
+  int q_of[PINN_MAX_DIRS];   // engine quantity (1 + direction index) of each residual direction role
+  int n_cols;                // mse
+  const float* T;
+  float thr, anchor; int xcol;
+  const float* scale;        // device term scales (null when no gradient wanted)
+  float* wg_sums;            // [grid][MAX_SUMS]
+  float* wg_grads;           // acc_lds: [grid][PP]; else [nrep][PP] (atomics)
+  int acc_lds, nrep;
+  int PW, PB;                // padded weight / bias float counts
+  int lds_acc_floats;        // floats reserved for the LDS gradient copy (0 if unused)
+};
+
+__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+template <int WP> __device__ __forceinline__ int w_off_p(int l) { return l == 0 ? 0 : WP * 16 + (l - 1) * WP * WP; }
+template <int WP> __device__ __forceinline__ int b_off_p(int l) { return l * WP; }
+
+// acc[c][MT] += sum_k Wl[16MT + m][k] * bin[c][k]   (Wl row-major, row stride 16*NT_IN)
+template <int NT_IN, int NT_OUT, int K1>
+__device__ __forceinline__ void gemm_chain(const float* __restrict__ Wl, const f4 (&bin)[K1][NT_IN],
+                                           f4 (&acc)[K1][NT_OUT], int m, int kq) {
+  constexpr int LDW = 16 * NT_IN;
+#pragma unroll
+  for (int MT = 0; MT < NT_OUT; ++MT) {
+    f4 a[NT_IN];
+#pragma unroll
+    for (int kt = 0; kt < NT_IN; ++kt)
+      a[kt] = *reinterpret_cast<const f4*>(Wl + (16 * MT + m) * LDW + 16 * kt + 4 * kq);
+#pragma unroll
+    for (int kt = 0; kt < NT_IN; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < K1; ++c) acc[c][MT] = mfma4(a[kt][r], bin[c][kt][r], acc[c][MT]);
+  }
+}
+
+template <int NT, int K1>
+__device__ __forceinline__ void init_bias(const float* __restrict__ b, f4 (&acc)[K1][NT], int q) {
+#pragma unroll
+  for (int MT = 0; MT < NT; ++MT) {
+    acc[0][MT] = *reinterpret_cast<const f4*>(b + 16 * MT + 4 * q);
+#pragma unroll
+    for (int c = 1; c < K1; ++c) acc[c][MT] = f4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+template <int NT, int K1>
+__device__ __forceinline__ void activate(f4 (&acc)[K1][NT], int act) {
+#pragma unroll
+  for (int MT = 0; MT < NT; ++MT)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float z = acc[0][MT][r];
+      float a, s;
+      if (act == PINN_ACT_TANH) { a = tanh_f32(z); s = 1.f - a * a; }
+      else { a = z > 0.f ? z : 0.01f * z; s = z > 0.f ? 1.f : 0.01f; }
+      acc[0][MT][r] = a;
+#pragma unroll
+      for (int c = 1; c < K1; ++c) acc[c][MT][r] *= s;
+    }
+}
+
+// adjoint of activate(): G holds (abar', abardot'_j) on entry, (zbar, zbardot_j) on exit
+template <int NT, int K1>
+__device__ __forceinline__ void activate_adjoint(f4 (&G)[K1][NT], const f4 (&A)[K1][NT], int act) {
+#pragma unroll
+  for (int MT = 0; MT < NT; ++MT)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float a = A[0][MT][r];
+      const float s = (act == PINN_ACT_TANH) ? 1.f - a * a : (a > 0.f ? 1.f : 0.01f);
+      float cross = 0.f;
+#pragma unroll
+      for (int c = 1; c < K1; ++c) {
+        cross = fmaf(G[c][MT][r], A[c][MT][r], cross);
+        G[c][MT][r] *= s;
+      }
+      float zb = s * G[0][MT][r];
+      if (act == PINN_ACT_TANH) zb = fmaf(-2.f * a, cross, zb);
+      G[0][MT][r] = zb;
+    }
+}
+
+template <int NT, int K1>
+__device__ __forceinline__ void spill(float* __restrict__ slot, const f4 (&v)[K1][NT], int lane) {
+#pragma unroll
+  for (int c = 0; c < K1; ++c)
+#pragma unroll
+    for (int MT = 0; MT < NT; ++MT) *reinterpret_cast<f4*>(slot + (c * NT + MT) * 256 + lane * 4) = v[c][MT];
+}
+template <int NT, int K1>
+__device__ __forceinline__ void unspill(const float* __restrict__ slot, f4 (&v)[K1][NT], int lane) {
+#pragma unroll
+  for (int c = 0; c < K1; ++c)
+#pragma unroll
+    for (int MT = 0; MT < NT; ++MT) v[c][MT] = *reinterpret_cast<const f4*>(slot + (c * NT + MT) * 256 + lane * 4);
+}
+
+// sum over the 16 lanes of a DPP row (= the 16 points of a tile); result valid in lane 15 of each row
+__device__ __forceinline__ float row_sum16(float v) {
+#define PINN_DPP_ADD(ctrl)                                                                              \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+  PINN_DPP_ADD(0x111);  // row_shr:1
+  PINN_DPP_ADD(0x112);  // row_shr:2
+  PINN_DPP_ADD(0x114);  // row_shr:4
+  PINN_DPP_ADD(0x118);  // row_shr:8
+#undef PINN_DPP_ADD
+  return v;
+}
+
+// acc-layout 16x16 block (features x points) -> operand layout of the weight-gradient GEMM:
+// lane (m = lane&15 feature, kq = lane>>4), element s  <-  value(feature m, point 4s + kq)
+__device__ __forceinline__ f4 transpose_block(float* __restrict__ tb, f4 v, int p, int q) {
+  *reinterpret_cast<f4*>(tb + p * TB_STRIDE + 4 * q) = v;     // row p holds the 16 features of point p
+  __builtin_amdgcn_wave_barrier();
+  f4 o;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) o[s] = tb[(4 * s + q) * TB_STRIDE + p];
+  __builtin_amdgcn_wave_barrier();
+  return o;
+}
+
+struct GradSink {
+  float* lacc;   // LDS copy (or null)
+  float* gacc;   // global replicated copy (atomics) when lacc is null
+  __device__ __forceinline__ void add(int idx, float v) const {
+    if (lacc) __hip_atomic_fetch_add(lacc + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_fetch_add(gacc + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+};
+
+// db[16MT + 4q + r] += sum_p Z[0][MT][r]
+template <int NT, int K1>
+__device__ __forceinline__ void bias_grad(const GradSink& sink, int boff, const f4 (&Z)[K1][NT], int p, int q) {
+#pragma unroll
+  for (int MT = 0; MT < NT; ++MT)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float s = row_sum16(Z[0][MT][r]);
+      if (p == 15) sink.add(boff + 16 * MT + 4 * q + r, s);
+    }
+}
+
+// dW[16MT + 4q + r][16NT + n] += sum_c sum_points Z[c][MT](feature, point) * A[c][NT](feature, point)
+// loadA(c, NT) returns the layer-input tile in acc layout.
+template <int MT_N, int NT_N, int K1, class LoadA>
+__device__ __forceinline__ void weight_grad(const GradSink& sink, int woff, int ld_in, const f4 (&Z)[K1][MT_N],
+                                            LoadA loadA, float* __restrict__ tb, int p, int q) {
+  f4 dw[MT_N][NT_N];
+#pragma unroll
+  for (int MT = 0; MT < MT_N; ++MT)
+#pragma unroll
+    for (int NT = 0; NT < NT_N; ++NT) dw[MT][NT] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < K1; ++c) {
+    f4 zt[MT_N], at[NT_N];
+#pragma unroll
+    for (int MT = 0; MT < MT_N; ++MT) zt[MT] = transpose_block(tb + (MT & 1) * TB_FLOATS, Z[c][MT], p, q);
+#pragma unroll
+    for (int NT = 0; NT < NT_N; ++NT) at[NT] = transpose_block(tb + (NT & 1) * TB_FLOATS, loadA(c, NT), p, q);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int MT = 0; MT < MT_N; ++MT)
+#pragma unroll
+        for (int NT = 0; NT < NT_N; ++NT) dw[MT][NT] = mfma4(zt[MT][s], at[NT][s], dw[MT][NT]);
+  }
+#pragma unroll
+  for (int MT = 0; MT < MT_N; ++MT)
+#pragma unroll
+    for (int NT = 0; NT < NT_N; ++NT)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sink.add(woff + (16 * MT + 4 * q + r) * ld_in + 16 * NT + p, dw[MT][NT][r]);
+}
+
+__device__ __forceinline__ float pick4(f4 v, int i) {
+  return i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : v[3]));
+}
+// output column o of the (single) output tile, for this lane's point
+__device__ __forceinline__ float gather_out(f4 tile, int o, int p) {
+  return __shfl(pick4(tile, o & 3), p + 16 * (o >> 2), 64);
+}
+template <int K1>
+__device__ __forceinline__ f4 pick_q(const f4 (&out)[K1][1], int qi) {
+  f4 v = out[0][0];
+#pragma unroll
+  for (int c = 1; c < K1; ++c) v = (qi == c) ? out[c][0] : v;
+  return v;
+}
+
+// Evaluate one residual family on the gathered jet; writes the adjoint tile G (acc layout).
+template <class RES, int K1, bool GRAD>
+__device__ __forceinline__ void residual_tile(const FusedParams& P, const f4 (&out)[K1][1], f4 (&G)[K1][1],
+                                              float (&sums)[MAX_SUMS], bool valid, bool masked, int p, int q) {
+  constexpr int NR = RES::NR, ND = RES::ND, NT = RES::NT;
+  float v[1 + ND][NR], g[1 + ND][NR], sq[NT], sc[NT];
+#pragma unroll
+  for (int c = 0; c <= ND; ++c) {
+    const f4 tile = (c == 0) ? out[0][0] : pick_q<K1>(out, P.q_of[c - 1]);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) v[c][r] = gather_out(tile, P.out_col[r], p);
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) sc[t] = GRAD ? P.scale[t] : 0.f;
+  if constexpr (std::is_same<RES, ResContinuity>::value)
+    RES::template eval<GRAD>(v, sc, g, sq, P.residual_id == PINN_RES_CONTINUITY_ONLY, masked, P.anchor);
+  else
+    RES::template eval<GRAD>(v, sc, g, sq);
+  if (valid && q == 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sums[t] += sq[t];
+  }
+  if (GRAD) {
+#pragma unroll
+    for (int ce = 0; ce < K1; ++ce)
+#pragma unroll
+      for (int r2 = 0; r2 < 4; ++r2) {
+        const int o = 4 * q + r2;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c <= ND; ++c) {
+          const int cq = (c == 0) ? 0 : P.q_of[c - 1];
+#pragma unroll
+          for (int r = 0; r < NR; ++r) acc += (cq == ce && P.out_col[r] == o) ? g[c][r] : 0.f;
+        }
+        G[ce][0][r2] = valid ? acc : 0.f;
+      }
+  }
+}
+
+template <int WP, int K1, bool GRAD>
+__global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused(const FusedParams P) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NTH = WP / 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = lane & 15, q = lane >> 4;
+  float* lacc = smem;
+  float* tb = smem + P.lds_acc_floats + wave * (TB_PER_WAVE * TB_FLOATS);
+  float* lsum = smem + P.lds_acc_floats + FUSED_WAVES * TB_PER_WAVE * TB_FLOATS;
+  const int PP = P.PW + P.PB;
+  GradSink sink;
+  sink.lacc = (GRAD && P.acc_lds) ? lacc : nullptr;
+  sink.gacc = (GRAD && !P.acc_lds) ? P.wg_grads + (int64_t)(blockIdx.x % P.nrep) * PP : nullptr;
+  if (GRAD && P.acc_lds) {
+    for (int i = threadIdx.x; i < PP; i += FUSED_THREADS) lacc[i] = 0.f;
+    __syncthreads();
+  }
+  float sums[MAX_SUMS];
+#pragma unroll
+  for (int j = 0; j < MAX_SUMS; ++j) sums[j] = 0.f;
+
+  const int gw = blockIdx.x * FUSED_WAVES + wave, nw = gridDim.x * FUSED_WAVES;
+  float* scr = P.scratch + (int64_t)gw * P.scratch_per_wave;
+  constexpr int SLOT = K1 * NTH * 256;  // floats per spilled layer
+  const int L = P.L, act = P.act;
+
+  for (int64_t tile = gw; tile < P.n_tiles; tile += nw) {
+    const int64_t pt = tile * 16 + p;
+    const bool valid = pt < P.N;
+    const int64_t ptc = valid ? pt : P.N - 1;
+    // ---- layer-0 input jet: features 4q + r of (x, unit tangents) --------------------------
+    f4 b0[K1][1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = 4 * q + r;
+      b0[0][0][r] = (f < P.d_in) ? P.X[ptc * P.d_in + f] : 0.f;
+#pragma unroll
+      for (int c = 1; c < K1; ++c) b0[c][0][r] = (f == P.dir_col[c - 1]) ? 1.f : 0.f;
+    }
+    // ---- forward chain ------------------------------------------------------------------------
+    f4 a[K1][NTH];
+    init_bias<NTH, K1>(P.Bp + b_off_p<WP>(0), a, q);
+    gemm_chain<1, NTH, K1>(P.Wp, b0, a, p, q);
+    activate<NTH, K1>(a, act);
+    if (GRAD) spill<NTH, K1>(scr, a, lane);
+    for (int l = 1; l < L; ++l) {
+      f4 nx[K1][NTH];
+      init_bias<NTH, K1>(P.Bp + b_off_p<WP>(l), nx, q);
+      gemm_chain<NTH, NTH, K1>(P.Wp + w_off_p<WP>(l), a, nx, p, q);
+      activate<NTH, K1>(nx, act);
+      if (GRAD) spill<NTH, K1>(scr + l * SLOT, nx, lane);
+#pragma unroll
+      for (int c = 0; c < K1; ++c)
+#pragma unroll
+        for (int MT = 0; MT < NTH; ++MT) a[c][MT] = nx[c][MT];
+    }
+    f4 out[K1][1];
+    init_bias<1, K1>(P.Bp + b_off_p<WP>(L), out, q);
+    gemm_chain<NTH, 1, K1>(P.Wp + w_off_p<WP>(L), a, out, p, q);
+
+    // ---- outputs / loss -----------------------------------------------------------------------
+    if (P.Y != nullptr && valid) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = 4 * q + r;
+        if (o < P.d_out) {
+          P.Y[pt * P.d_out + o] = out[0][0][r];
+          if (P.dY != nullptr) {
+#pragma unroll
+            for (int c = 1; c < K1; ++c) P.dY[((int64_t)(c - 1) * P.N + pt) * P.d_out + o] = out[c][0][r];
+          }
+        }
+      }
+    }
+    f4 G[K1][1];
+#pragma unroll
+    for (int c = 0; c < K1; ++c) G[c][0] = f4{0.f, 0.f, 0.f, 0.f};
+    if (P.loss_kind == 1) {
+      if (P.residual_id == PINN_RES_NAVIER_STOKES) {
+        if constexpr (K1 >= 4) residual_tile<ResNavierStokes, K1, GRAD>(P, out, G, sums, valid, false, p, q);
+      } else if (P.residual_id == PINN_RES_PHYSICS_EQUATION) {
+        if constexpr (K1 >= 3) residual_tile<ResPhysicsEquation, K1, GRAD>(P, out, G, sums, valid, false, p, q);
+      } else {
+        if constexpr (K1 >= 3) {
+          const bool masked = P.residual_id == PINN_RES_CONTINUITY_ONLY && P.X[ptc * P.d_in + P.xcol] < P.thr;
+          residual_tile<ResContinuity, K1, GRAD>(P, out, G, sums, valid, masked, p, q);
+        }
+      }
+    } else if (P.loss_kind == 2) {
+#pragma unroll
+      for (int j = 0; j < PINN_MAX_ROLES; ++j) {
+        if (j < P.n_cols) {
+          const float y = gather_out(out[0][0], P.out_col[j], p);
+          const float d = P.T[ptc * P.n_cols + j] - y;                  // train.py:141 (true - pred)
+          if (valid && q == 0) sums[j] += d * d;
+          if (GRAD) {
+            const float gj = valid ? -2.f * P.scale[j] * d : 0.f;
+#pragma unroll
+            for (int r2 = 0; r2 < 4; ++r2) G[0][0][r2] += (P.out_col[j] == 4 * q + r2) ? gj : 0.f;
+          }
+        }
+      }
+    }
+
+    // ---- reverse sweep ------------------------------------------------------------------------
+    if constexpr (GRAD) {
+      // output layer L (linear): zbar = G; input = a_L (slot L-1)
+      const float* aL = scr + (L - 1) * SLOT;
+      bias_grad<1, K1>(sink, P.PW + b_off_p<WP>(L), G, p, q);
+      weight_grad<1, NTH, K1>(sink, w_off_p<WP>(L), WP, G,
+                              [&](int c, int NT) { return *reinterpret_cast<const f4*>(aL + (c * NTH + NT) * 256 + lane * 4); },
+                              tb, p, q);
+      f4 g[K1][NTH];
+#pragma unroll
+      for (int c = 0; c < K1; ++c)
+#pragma unroll
+        for (int MT = 0; MT < NTH; ++MT) g[c][MT] = f4{0.f, 0.f, 0.f, 0.f};
+      gemm_chain<1, NTH, K1>(P.WTp + w_off_p<WP>(L), G, g, p, q);
+      for (int l = L - 1; l >= 1; --l) {
+        // hidden layer l: output a_{l+1} (slot l), input a_l (slot l-1)
+        f4 ao[K1][NTH];
+        unspill<NTH, K1>(scr + l * SLOT, ao, lane);
+        activate_adjoint<NTH, K1>(g, ao, act);
+        bias_grad<NTH, K1>(sink, P.PW + b_off_p<WP>(l), g, p, q);
+        const float* ai = scr + (l - 1) * SLOT;
+        weight_grad<NTH, NTH, K1>(sink, w_off_p<WP>(l), WP, g,
+                                  [&](int c, int NT) { return *reinterpret_cast<const f4*>(ai + (c * NTH + NT) * 256 + lane * 4); },
+                                  tb, p, q);
+        f4 g2[K1][NTH];
+#pragma unroll
+        for (int c = 0; c < K1; ++c)
+#pragma unroll
+          for (int MT = 0; MT < NTH; ++MT) g2[c][MT] = f4{0.f, 0.f, 0.f, 0.f};
+        gemm_chain<NTH, NTH, K1>(P.WTp + w_off_p<WP>(l), g, g2, p, q);
+#pragma unroll
+        for (int c = 0; c < K1; ++c)
+#pragma unroll
+          for (int MT = 0; MT < NTH; ++MT) g[c][MT] = g2[c][MT];
+      }
+      {  // layer 0: output a_1 (slot 0), input = (x, unit tangents)
+        f4 ao[K1][NTH];
+        unspill<NTH, K1>(scr, ao, lane);
+        activate_adjoint<NTH, K1>(g, ao, act);
+        bias_grad<NTH, K1>(sink, P.PW + b_off_p<WP>(0), g, p, q);
+        weight_grad<NTH, 1, K1>(sink, 0, 16, g, [&](int c, int) { return b0[c][0]; }, tb, p, q);
+      }
+    }
+  }
+
+  // ---- per-workgroup reductions ------------------------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < MAX_SUMS; ++j) {
+    float v = sums[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) lsum[wave * MAX_SUMS + j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < MAX_SUMS) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < FUSED_WAVES; ++w) v += lsum[w * MAX_SUMS + threadIdx.x];
+    P.wg_sums[(int64_t)blockIdx.x * MAX_SUMS + threadIdx.x] = v;
+  }
+  if (GRAD && P.acc_lds) {
+    float* dst = P.wg_grads + (int64_t)blockIdx.x * PP;
+    for (int i = threadIdx.x; i < PP; i += FUSED_THREADS) dst[i] = lacc[i];
+  }
+}
+
+// launcher implemented once per WP in pinn_fused_wXX.hip
+template <int WP>
+int launch_fused(int K1, bool grad, const FusedParams& P, int grid, size_t lds_bytes, hipStream_t s);
+
+}  // namespace pinn

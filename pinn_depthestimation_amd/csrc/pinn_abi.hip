@@ -172,7 +172,7 @@ static int32_t residual_impl(const pinn_desc* desc, const pinn_residual_spec* sp
   LossReq rq; memset(&rq, 0, sizeof(rq));
   rq.kind = 0; rq.spec = *spec; rq.scale = term_scale; rq.sums = term_sums;
   rq.grad = want_grad ? grad_flat : nullptr; rq.n_terms = residual_terms(spec->residual_id);
-  if (N == 0) { hipMemsetAsync(term_sums, 0, rq.n_terms * sizeof(float), (hipStream_t)stream); return PINN_OK; }
+  if (N == 0) { (void)hipMemsetAsync(term_sums, 0, rq.n_terms * sizeof(float), (hipStream_t)stream); return PINN_OK; }
   bool fused = use_fused(desc, n, &rc); if (rc) return rc;
   return fused ? fused_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream)
                : generic_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream);
@@ -204,7 +204,7 @@ int32_t pinn_mse_loss_grad(const pinn_desc* desc, const float* params, const flo
     if (out_col[j] < 0 || out_col[j] >= n.d_out) { set_error("out_col[%d]=%d out of range", j, out_col[j]); return PINN_ERR_INVALID; }
     rq.out_col[j] = out_col[j];
   }
-  if (N == 0) { hipMemsetAsync(col_sums, 0, n_cols * sizeof(float), (hipStream_t)stream); return PINN_OK; }
+  if (N == 0) { (void)hipMemsetAsync(col_sums, 0, n_cols * sizeof(float), (hipStream_t)stream); return PINN_OK; }
   n.k = 0; n.K1 = 1;  // the fidelity term needs no input derivatives
   bool fused = use_fused(desc, n, &rc); if (rc) return rc;
   return fused ? fused_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream)

@@ -1,10 +1,236 @@
-// pinn_fused.hip — placeholder until the MFMA chain engine lands
-#include "common.h"
+// pinn_fused.hip — host side of the fused MFMA engine: weight packing, workspace carve,
+// launch geometry, cross-workgroup reductions.  Kernel: fused_kernel.h.
+#include <type_traits>
+#include "fused_kernel.h"
+
 namespace pinn {
-bool fused_supports(const Net&) { return false; }
-int64_t fused_workspace_bytes(const Net&, int64_t) { return -1; }
-int fused_forward(const Net&, const float*, const float*, int64_t, float*, float*, void*, int64_t, hipStream_t) {
-  set_error("fused engine not built"); return PINN_ERR_UNSUPPORTED; }
-int fused_loss(const Net&, const LossReq&, const float*, const float*, int64_t, void*, int64_t, hipStream_t) {
-  set_error("fused engine not built"); return PINN_ERR_UNSUPPORTED; }
+
+namespace {
+
+int padded_width(int W) { return W <= 16 ? 16 : (W <= 32 ? 32 : 64); }
+
+struct Geo {
+  int WP, NTH, PW, PB, PP;
+  int64_t slot_floats_k4;   // per spilled layer at K1 = 4
+};
+Geo geo_of(const Net& n) {
+  Geo g;
+  g.WP = padded_width(n.W); g.NTH = g.WP / 16;
+  g.PW = g.WP * 16 + (n.L - 1) * g.WP * g.WP + 16 * g.WP;
+  g.PB = n.L * g.WP + 16;
+  g.PP = g.PW + g.PB;
+  g.slot_floats_k4 = (int64_t)4 * g.NTH * 256;
+  return g;
 }
+
+int cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    else cus = 256;
+  }
+  return cus;
+}
+
+constexpr int64_t LDS_LIMIT = 160 * 1024;
+constexpr int NREP = 16;   // replicated global accumulators when the gradient does not fit LDS
+
+int64_t lds_fixed_bytes() { return (int64_t)(FUSED_WAVES * TB_PER_WAVE * TB_FLOATS + FUSED_WAVES * MAX_SUMS) * 4; }
+bool fits_lds(const Geo& g) { return (int64_t)g.PP * 4 + lds_fixed_bytes() <= LDS_LIMIT; }
+
+int grid_for(int64_t n_tiles, bool one_per_cu) {
+  int64_t want = (n_tiles + FUSED_WAVES - 1) / FUSED_WAVES;
+  int64_t cap = (int64_t)cu_count() * (one_per_cu ? 1 : 2);
+  if (want < 1) want = 1;
+  return (int)(want < cap ? want : cap);
+}
+
+struct WsLayout {
+  int64_t wp, wtp, bp, scratch, wg_sums, wg_grads, total;
+  int max_grid;
+};
+int64_t al(int64_t v) { return (v + 255) & ~(int64_t)255; }
+
+WsLayout ws_layout(const Net& n, const Geo& g, int64_t N) {
+  WsLayout w;
+  const int64_t n_tiles = (N + 15) / 16;
+  w.max_grid = grid_for(n_tiles, false);
+  int64_t off = 0;
+  w.wp = off; off += al((int64_t)g.PW * 4);
+  w.wtp = off; off += al((int64_t)g.PW * 4);
+  w.bp = off; off += al((int64_t)g.PB * 4);
+  w.scratch = off; off += al((int64_t)w.max_grid * FUSED_WAVES * n.L * g.slot_floats_k4 * 4);
+  w.wg_sums = off; off += al((int64_t)w.max_grid * MAX_SUMS * 4);
+  const int64_t copies = fits_lds(g) ? w.max_grid : NREP;
+  w.wg_grads = off; off += al(copies * g.PP * 4);
+  w.total = off;
+  return w;
+}
+
+// flat torch-layout parameters -> padded row-major W, padded transposed W, padded bias
+__global__ void k_pack(Net n, int WP, const float* __restrict__ params, float* __restrict__ Wp,
+                       float* __restrict__ WTp, float* __restrict__ Bp, int PW, int PB) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < PW) {
+    // which layer block does padded index i fall in?
+    int l, rem;
+    if (i < WP * 16) { l = 0; rem = i; }
+    else {
+      const int j = i - WP * 16;
+      l = 1 + j / (WP * WP); rem = j % (WP * WP);
+      if (l > n.L) { l = n.L; rem = i - (WP * 16 + (n.L - 1) * WP * WP); }
+    }
+    const int inP = (l == 0) ? 16 : WP, outP = (l == n.L) ? 16 : WP;
+    const int in_d = n.in_dim(l), out_d = n.out_dim(l);
+    const int base = i - rem;
+    {  // row-major [out][in]
+      const int o = rem / inP, c = rem % inP;
+      Wp[i] = (o < out_d && c < in_d) ? params[n.w_off(l) + (int64_t)o * in_d + c] : 0.f;
+    }
+    {  // transposed [in][out]
+      const int c = rem / outP, o = rem % outP;
+      WTp[base + rem] = (o < out_d && c < in_d) ? params[n.w_off(l) + (int64_t)o * in_d + c] : 0.f;
+    }
+  }
+  if (i < PB) {
+    int l = i / WP, o = i % WP;
+    if (l >= n.L) { l = n.L; o = i - n.L * WP; }
+    Bp[i] = (o < n.out_dim(l)) ? params[n.b_off(l) + o] : 0.f;
+  }
+}
+
+__global__ void k_reduce_sums(const float* __restrict__ wg_sums, int grid, int nt, float* __restrict__ out) {
+  const int t = blockIdx.x;
+  __shared__ double red[256];
+  double v = 0.0;
+  for (int b = threadIdx.x; b < grid; b += 256) v += (double)wg_sums[(int64_t)b * MAX_SUMS + t];
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && t < nt) out[t] = (float)red[0];
+}
+
+// grad_flat[real index] += sum over copies of the padded per-workgroup gradients (fixed order)
+__global__ void k_reduce_grads(Net n, int WP, const float* __restrict__ wg, int copies, int PP, int PW,
+                               float* __restrict__ grad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n.n_params()) return;
+  int l = 0; int64_t off = 0;
+  for (;; ++l) {
+    const int64_t sz = (int64_t)n.in_dim(l) * n.out_dim(l) + n.out_dim(l);
+    if (i < off + sz) break;
+    off += sz;
+  }
+  const int64_t r = i - off;
+  const int in_d = n.in_dim(l), out_d = n.out_dim(l);
+  const int inP = (l == 0) ? 16 : WP;
+  const int wo = (l == 0) ? 0 : WP * 16 + (l - 1) * WP * WP;
+  int pidx;
+  if (r < (int64_t)in_d * out_d) pidx = wo + (int)(r / in_d) * inP + (int)(r % in_d);
+  else pidx = PW + l * WP + (int)(r - (int64_t)in_d * out_d);
+  float s = 0.f;
+  for (int c = 0; c < copies; ++c) s += wg[(int64_t)c * PP + pidx];
+  grad[i] += s;
+}
+
+int run(const Net& n, bool grad, const LossReq* rq, const float* params, const float* X, int64_t N, float* Y,
+        float* dY, void* ws, int64_t ws_bytes, hipStream_t s) {
+  const Geo g = geo_of(n);
+  const WsLayout w = ws_layout(n, g, N);
+  if (!ws || ws_bytes < w.total) {
+    set_error("workspace too small: need %lld bytes, got %lld", (long long)w.total, (long long)ws_bytes);
+    return PINN_ERR_WORKSPACE;
+  }
+  char* base = (char*)ws;
+  FusedParams P;
+  memset(&P, 0, sizeof(P));
+  P.d_in = n.d_in; P.d_out = n.d_out; P.L = n.L; P.act = n.act;
+  for (int j = 0; j < PINN_MAX_DIRS; ++j) P.dir_col[j] = n.dir_col[j];
+  P.N = N; P.n_tiles = (N + 15) / 16;
+  P.X = X;
+  P.Wp = (const float*)(base + w.wp); P.WTp = (const float*)(base + w.wtp); P.Bp = (const float*)(base + w.bp);
+  P.scratch = (float*)(base + w.scratch);
+  P.scratch_per_wave = (int64_t)n.L * n.K1 * g.NTH * 256;
+  P.Y = Y; P.dY = dY;
+  P.wg_sums = (float*)(base + w.wg_sums);
+  P.wg_grads = (float*)(base + w.wg_grads);
+  P.PW = g.PW; P.PB = g.PB;
+  P.acc_lds = (grad && fits_lds(g)) ? 1 : 0;
+  P.nrep = NREP;
+  P.lds_acc_floats = P.acc_lds ? g.PP : 0;
+  int n_terms = 0;
+  if (rq) {
+    P.loss_kind = rq->kind == 1 ? 2 : 1;
+    P.scale = rq->scale;
+    n_terms = rq->n_terms;
+    if (rq->kind == 1) {
+      P.n_cols = rq->n_cols; P.T = rq->T;
+      for (int j = 0; j < PINN_MAX_ROLES; ++j) P.out_col[j] = rq->out_col[j];
+    } else {
+      P.residual_id = rq->spec.residual_id;
+      for (int j = 0; j < PINN_MAX_ROLES; ++j) P.out_col[j] = rq->spec.out_col[j];
+      for (int d = 0; d < PINN_MAX_DIRS; ++d) P.q_of[d] = 1 + rq->spec.dir_of[d];
+      P.thr = rq->spec.param[0]; P.anchor = rq->spec.param[1];
+      P.xcol = n.dir_col[rq->spec.dir_of[0]];
+    }
+  }
+  const int grid = grid_for(P.n_tiles, grad && P.acc_lds);
+  const size_t lds = (size_t)P.lds_acc_floats * 4 + (size_t)lds_fixed_bytes();
+
+  const int packN = g.PW > g.PB ? g.PW : g.PB;
+  hipLaunchKernelGGL(k_pack, dim3((packN + 255) / 256), dim3(256), 0, s, n, g.WP, params, (float*)(base + w.wp),
+                     (float*)(base + w.wtp), (float*)(base + w.bp), g.PW, g.PB);
+  if (grad && !P.acc_lds) {
+    if (hipMemsetAsync(P.wg_grads, 0, (size_t)NREP * g.PP * 4, s) != hipSuccess) {
+      set_error("hipMemsetAsync failed"); return PINN_ERR_LAUNCH;
+    }
+  }
+  int rc;
+  switch (g.WP) {
+    case 16: rc = launch_fused<16>(n.K1, grad, P, grid, lds, s); break;
+    case 32: rc = launch_fused<32>(n.K1, grad, P, grid, lds, s); break;
+    default: rc = launch_fused<64>(n.K1, grad, P, grid, lds, s); break;
+  }
+  if (rc) return rc;
+  if (rq) {
+    hipLaunchKernelGGL(k_reduce_sums, dim3(n_terms), dim3(256), 0, s, (const float*)P.wg_sums, grid, n_terms,
+                       rq->sums);
+    if (grad) {
+      const int copies = P.acc_lds ? grid : NREP;
+      const int64_t np = n.n_params();
+      hipLaunchKernelGGL(k_reduce_grads, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, n, g.WP,
+                         (const float*)P.wg_grads, copies, g.PP, g.PW, rq->grad);
+    }
+  }
+  return check_launch("fused reductions");
+}
+
+}  // namespace
+
+bool fused_supports(const Net& n) {
+  return n.W <= 64 && n.d_in <= 16 && n.d_out <= 16 && n.L >= 1 && n.K1 >= 1 && n.K1 <= 4;
+}
+
+int64_t fused_workspace_bytes(const Net& n, int64_t N) {
+  if (!fused_supports(n)) return -1;
+  return ws_layout(n, geo_of(n), N > 0 ? N : 1).total;
+}
+
+int fused_forward(const Net& n, const float* params, const float* X, int64_t N, float* Y, float* dY, void* ws,
+                  int64_t ws_bytes, hipStream_t s) {
+  return run(n, false, nullptr, params, X, N, Y, dY, ws, ws_bytes, s);
+}
+
+int fused_loss(const Net& n, const LossReq& rq, const float* params, const float* X, int64_t N, void* ws,
+               int64_t ws_bytes, hipStream_t s) {
+  const bool grad = rq.grad != nullptr;
+  if (grad && n.K1 == 2) { set_error("fused gradient kernels exist for K1 in {1,3,4}"); return PINN_ERR_UNSUPPORTED; }
+  return run(n, grad, &rq, params, X, N, nullptr, nullptr, ws, ws_bytes, s);
+}
+
+}  // namespace pinn

@@ -1,0 +1,38 @@
+// pinn_fused_w32.hip — instantiations of the fused MFMA chain kernel for padded hidden width 32
+#include <type_traits>
+#include "fused_kernel.h"
+
+namespace pinn {
+
+template <int K1, bool GRAD>
+static int launch_one(const FusedParams& P, int grid, size_t lds, hipStream_t s) {
+  auto kern = k_fused<32, K1, GRAD>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e)); return PINN_ERR_LAUNCH; }
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(FUSED_THREADS), lds, s, P);
+  return check_launch("fused kernel (WP=32)");
+}
+
+template <>
+int launch_fused<32>(int K1, bool grad, const FusedParams& P, int grid, size_t lds, hipStream_t s) {
+  if (!grad) {
+    switch (K1) {
+      case 1: return launch_one<1, false>(P, grid, lds, s);
+      case 2: return launch_one<2, false>(P, grid, lds, s);
+      case 3: return launch_one<3, false>(P, grid, lds, s);
+      case 4: return launch_one<4, false>(P, grid, lds, s);
+    }
+  } else {
+    switch (K1) {
+      case 1: return launch_one<1, true>(P, grid, lds, s);
+      case 3: return launch_one<3, true>(P, grid, lds, s);
+      case 4: return launch_one<4, true>(P, grid, lds, s);
+    }
+  }
+  set_error("fused engine: no kernel for K1=%d grad=%d", K1, (int)grad);
+  return PINN_ERR_UNSUPPORTED;
+}
+
+}  // namespace pinn

@@ -379,7 +379,7 @@ int run_loss(const Net& n, const LossReq& rq, const float* params, const float* 
   float* G = (float*)(ws + lo.g0);
   float* partial = (float*)(ws + lo.partial);
   const bool want_grad = rq.grad != nullptr;
-  if (want_grad) hipMemsetAsync(G, 0, (size_t)K1 * n.d_out * N * 4, s);
+  if (want_grad) (void)hipMemsetAsync(G, 0, (size_t)K1 * n.d_out * N * 4, s);
   int nt_stride = 0;
   if (rq.kind == 1) {
     MseMap mm; mm.n_cols = rq.n_cols;

@@ -49,7 +49,7 @@ def rel_l2(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
 
-ENGINES = [ENGINE_GENERIC]
+ENGINES = [ENGINE_GENERIC, ENGINE_FUSED]
 
 
 @pytest.mark.parametrize("engine", ENGINES)
