@@ -7,7 +7,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpinn_hip.so")
+LIB_PATH = os.environ.get("PINN_HIP_LIB", os.path.join(_HERE, "libpinn_hip.so"))  # override: kernel experiments
 CSRC = os.path.join(_HERE, "csrc")
 
 PINN_MAX_DIRS = 3

@@ -101,16 +101,16 @@ __device__ __forceinline__ void init_bias(const float* __restrict__ b, f4 (&acc)
   }
 }
 
+// tanh only: every reference config uses init_type 'xavier' (dnn.py:18-19); LeakyReLU nets run
+// on the generic engine.
 template <int NT, int K1>
-__device__ __forceinline__ void activate(f4 (&acc)[K1][NT], int act) {
+__device__ __forceinline__ void activate(f4 (&acc)[K1][NT]) {
 #pragma unroll
   for (int MT = 0; MT < NT; ++MT)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float z = acc[0][MT][r];
-      float a, s;
-      if (act == PINN_ACT_TANH) { a = tanh_f32(z); s = 1.f - a * a; }
-      else { a = z > 0.f ? z : 0.01f * z; s = z > 0.f ? 1.f : 0.01f; }
+      const float a = tanh_f32(acc[0][MT][r]);
+      const float s = fmaf(-a, a, 1.f);
       acc[0][MT][r] = a;
 #pragma unroll
       for (int c = 1; c < K1; ++c) acc[c][MT][r] *= s;
@@ -119,22 +119,20 @@ __device__ __forceinline__ void activate(f4 (&acc)[K1][NT], int act) {
 
 // adjoint of activate(): G holds (abar', abardot'_j) on entry, (zbar, zbardot_j) on exit
 template <int NT, int K1>
-__device__ __forceinline__ void activate_adjoint(f4 (&G)[K1][NT], const f4 (&A)[K1][NT], int act) {
+__device__ __forceinline__ void activate_adjoint(f4 (&G)[K1][NT], const f4 (&A)[K1][NT]) {
 #pragma unroll
   for (int MT = 0; MT < NT; ++MT)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float a = A[0][MT][r];
-      const float s = (act == PINN_ACT_TANH) ? 1.f - a * a : (a > 0.f ? 1.f : 0.01f);
+      const float s = fmaf(-a, a, 1.f);
       float cross = 0.f;
 #pragma unroll
       for (int c = 1; c < K1; ++c) {
         cross = fmaf(G[c][MT][r], A[c][MT][r], cross);
         G[c][MT][r] *= s;
       }
-      float zb = s * G[0][MT][r];
-      if (act == PINN_ACT_TANH) zb = fmaf(-2.f * a, cross, zb);
-      G[0][MT][r] = zb;
+      G[0][MT][r] = fmaf(-2.f * a, cross, s * G[0][MT][r]);   // tanh'' = -2 a (1 - a^2)
     }
 }
 
@@ -177,32 +175,59 @@ __device__ __forceinline__ f4 transpose_block(float* __restrict__ tb, f4 v, int 
   return o;
 }
 
+constexpr int MAX_LOCKS = 128;
+
+// Where dW/db contributions go.
+//  LDSACC: the workgroup's LDS copy of the padded gradient.  LDS fp32 atomics (ds_add_f32)
+//    measured ~150 cycles per wave-instruction on gfx950 and dominated the kernel; a plain
+//    ds_read_b128 / v_add / ds_write_b128 is ~free.  So each layer's block is guarded by a
+//    wave-level spin lock (one ds_cmpst by lane 0) and updated with plain vector RMW.
+//  !LDSACC (gradient too large for LDS): one of NREP global copies, global_atomic_add_f32.
+// Weight blocks are stored fragment-native: tile (MT, NT), lane, reg r holds
+// dW[16MT + 4(lane>>4) + r][16NT + (lane&15)]  at  woff + ((MT*NT_N + NT)*64 + lane)*4 + r.
+template <bool LDSACC>
 struct GradSink {
-  float* lacc;   // LDS copy (or null)
-  float* gacc;   // global replicated copy (atomics) when lacc is null
-  __device__ __forceinline__ void add(int idx, float v) const {
-    if (lacc) __hip_atomic_fetch_add(lacc + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else __hip_atomic_fetch_add(gacc + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float* acc;
+  int* locks;
+  __device__ __forceinline__ void lock(int l, int lane) const {
+    if constexpr (LDSACC) {
+      if (lane == 0) {
+        int expected = 0;
+        while (!__hip_atomic_compare_exchange_strong(locks + l, &expected, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WORKGROUP)) {
+          expected = 0;
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __device__ __forceinline__ void unlock(int l, int lane) const {
+    if constexpr (LDSACC) {
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(locks + l, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  __device__ __forceinline__ void add4(int idx, f4 v) const {   // idx: float index, multiple of 4
+    if constexpr (LDSACC) {
+      f4* ptr = reinterpret_cast<f4*>(acc + idx);
+      *ptr = *ptr + v;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) __hip_atomic_fetch_add(acc + idx + r, v[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 };
 
-// db[16MT + 4q + r] += sum_p Z[0][MT][r]
-template <int NT, int K1>
-__device__ __forceinline__ void bias_grad(const GradSink& sink, int boff, const f4 (&Z)[K1][NT], int p, int q) {
-#pragma unroll
-  for (int MT = 0; MT < NT; ++MT)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float s = row_sum16(Z[0][MT][r]);
-      if (p == 15) sink.add(boff + 16 * MT + 4 * q + r, s);
-    }
-}
-
 // dW[16MT + 4q + r][16NT + n] += sum_c sum_points Z[c][MT](feature, point) * A[c][NT](feature, point)
+// db[16MT + 4q + r]           += sum_points Z[0][MT]
 // loadA(c, NT) returns the layer-input tile in acc layout.
-template <int MT_N, int NT_N, int K1, class LoadA>
-__device__ __forceinline__ void weight_grad(const GradSink& sink, int woff, int ld_in, const f4 (&Z)[K1][MT_N],
-                                            LoadA loadA, float* __restrict__ tb, int p, int q) {
+template <int MT_N, int NT_N, int K1, class Sink, class LoadA>
+__device__ __forceinline__ void weight_grad(const Sink& sink, int layer, int woff, int boff, const f4 (&Z)[K1][MT_N],
+                                            LoadA loadA, float* __restrict__ tb, int lane) {
+  const int p = lane & 15, q = lane >> 4;
   f4 dw[MT_N][NT_N];
 #pragma unroll
   for (int MT = 0; MT < MT_N; ++MT)
@@ -222,12 +247,21 @@ __device__ __forceinline__ void weight_grad(const GradSink& sink, int woff, int 
 #pragma unroll
         for (int NT = 0; NT < NT_N; ++NT) dw[MT][NT] = mfma4(zt[MT][s], at[NT][s], dw[MT][NT]);
   }
+  f4 bs[MT_N];   // bias partial sums over the tile's 16 points (valid in lanes p == 15)
 #pragma unroll
   for (int MT = 0; MT < MT_N; ++MT)
 #pragma unroll
-    for (int NT = 0; NT < NT_N; ++NT)
+    for (int r = 0; r < 4; ++r) bs[MT][r] = row_sum16(Z[0][MT][r]);
+  sink.lock(layer, lane);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sink.add(woff + (16 * MT + 4 * q + r) * ld_in + 16 * NT + p, dw[MT][NT][r]);
+  for (int MT = 0; MT < MT_N; ++MT)
+#pragma unroll
+    for (int NT = 0; NT < NT_N; ++NT) sink.add4(woff + ((MT * NT_N + NT) * 64 + lane) * 4, dw[MT][NT]);
+  if (p == 15) {
+#pragma unroll
+    for (int MT = 0; MT < MT_N; ++MT) sink.add4(boff + 16 * MT + 4 * q, bs[MT]);
+  }
+  sink.unlock(layer, lane);
 }
 
 __device__ __forceinline__ float pick4(f4 v, int i) {
@@ -245,10 +279,45 @@ __device__ __forceinline__ f4 pick_q(const f4 (&out)[K1][1], int qi) {
   return v;
 }
 
+// Per-lane lookup built once per kernel: which role (residual output role / mse target column)
+// lands in this lane's accumulator register r2 (-1: none), and which residual quantity maps to
+// engine quantity ce (-1: none).  Kept as small integers so that nothing but these is hoisted
+// out of the tile loop (hoisted lane predicates would each pin an SGPR pair).
+template <int K1>
+struct ScatterMap {
+  int role_of[4];
+  int cinv[K1];
+};
+
+// roles' adjoints g[c][r] (identical in all four lane groups) -> adjoint tile G in acc layout,
+// through the wave-private LDS pad (idle at this point): row (c*NR + r) holds the 16 points.
+template <int K1, int NC, int NR>
+__device__ __forceinline__ void scatter_adjoint(float* __restrict__ tb, const float (&g)[NC][NR],
+                                                const ScatterMap<K1>& sm, f4 (&G)[K1][1], bool valid, int p, int q) {
+  if (q == 0) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int r = 0; r < NR; ++r) tb[(c * NR + r) * 16 + p] = g[c][r];
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int ce = 0; ce < K1; ++ce)
+#pragma unroll
+    for (int r2 = 0; r2 < 4; ++r2) {
+      const int ci = sm.cinv[ce], ro = sm.role_of[r2];
+      const bool ok = valid && ci >= 0 && ci < NC && ro >= 0;
+      const float val = tb[ok ? (ci * NR + ro) * 16 + p : p];
+      G[ce][0][r2] = ok ? val : 0.f;
+    }
+  __builtin_amdgcn_wave_barrier();
+}
+
 // Evaluate one residual family on the gathered jet; writes the adjoint tile G (acc layout).
 template <class RES, int K1, bool GRAD>
 __device__ __forceinline__ void residual_tile(const FusedParams& P, const f4 (&out)[K1][1], f4 (&G)[K1][1],
-                                              float (&sums)[MAX_SUMS], bool valid, bool masked, int p, int q) {
+                                              float (&sums)[MAX_SUMS], const ScatterMap<K1>& sm,
+                                              float* __restrict__ tb, bool valid, bool masked, int p, int q) {
   constexpr int NR = RES::NR, ND = RES::ND, NT = RES::NT;
   float v[1 + ND][NR], g[1 + ND][NR], sq[NT], sc[NT];
 #pragma unroll
@@ -267,74 +336,81 @@ __device__ __forceinline__ void residual_tile(const FusedParams& P, const f4 (&o
 #pragma unroll
     for (int t = 0; t < NT; ++t) sums[t] += sq[t];
   }
-  if (GRAD) {
-#pragma unroll
-    for (int ce = 0; ce < K1; ++ce)
-#pragma unroll
-      for (int r2 = 0; r2 < 4; ++r2) {
-        const int o = 4 * q + r2;
-        float acc = 0.f;
-#pragma unroll
-        for (int c = 0; c <= ND; ++c) {
-          const int cq = (c == 0) ? 0 : P.q_of[c - 1];
-#pragma unroll
-          for (int r = 0; r < NR; ++r) acc += (cq == ce && P.out_col[r] == o) ? g[c][r] : 0.f;
-        }
-        G[ce][0][r2] = valid ? acc : 0.f;
-      }
-  }
+  if constexpr (GRAD) scatter_adjoint<K1, 1 + ND, NR>(tb, g, sm, G, valid, p, q);
 }
 
-template <int WP, int K1, bool GRAD>
+template <int WP, int K1, bool GRAD, bool LDSACC>
 __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused(const FusedParams P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NTH = WP / 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = lane & 15, q = lane >> 4;
   float* lacc = smem;
-  float* tb = smem + P.lds_acc_floats + wave * (TB_PER_WAVE * TB_FLOATS);
-  float* lsum = smem + P.lds_acc_floats + FUSED_WAVES * TB_PER_WAVE * TB_FLOATS;
+  int* locks = reinterpret_cast<int*>(smem + P.lds_acc_floats);
+  float* tb = smem + P.lds_acc_floats + MAX_LOCKS + wave * (TB_PER_WAVE * TB_FLOATS);
+  float* lsum = smem + P.lds_acc_floats + MAX_LOCKS + FUSED_WAVES * TB_PER_WAVE * TB_FLOATS;
   const int PP = P.PW + P.PB;
-  GradSink sink;
-  sink.lacc = (GRAD && P.acc_lds) ? lacc : nullptr;
-  sink.gacc = (GRAD && !P.acc_lds) ? P.wg_grads + (int64_t)(blockIdx.x % P.nrep) * PP : nullptr;
-  if (GRAD && P.acc_lds) {
+  GradSink<LDSACC> sink;
+  sink.acc = LDSACC ? lacc : P.wg_grads + (int64_t)(blockIdx.x % P.nrep) * PP;
+  sink.locks = locks;
+  if (GRAD && LDSACC) {
     for (int i = threadIdx.x; i < PP; i += FUSED_THREADS) lacc[i] = 0.f;
+    if (threadIdx.x < MAX_LOCKS) locks[threadIdx.x] = 0;
     __syncthreads();
   }
   float sums[MAX_SUMS];
 #pragma unroll
   for (int j = 0; j < MAX_SUMS; ++j) sums[j] = 0.f;
 
+  ScatterMap<K1> sm;
+  {
+    const int n_roles = P.loss_kind == 2 ? P.n_cols : PINN_MAX_ROLES;
+#pragma unroll
+    for (int r2 = 0; r2 < 4; ++r2) {
+      int ro = -1;
+      for (int r = PINN_MAX_ROLES - 1; r >= 0; --r) ro = (r < n_roles && P.out_col[r] == 4 * q + r2) ? r : ro;
+      sm.role_of[r2] = ro;
+    }
+    sm.cinv[0] = 0;
+#pragma unroll
+    for (int ce = 1; ce < K1; ++ce) {
+      int ci = -1;
+      for (int d = PINN_MAX_DIRS - 1; d >= 0; --d) ci = (P.q_of[d] == ce) ? 1 + d : ci;
+      sm.cinv[ce] = ci;
+    }
+  }
   const int gw = blockIdx.x * FUSED_WAVES + wave, nw = gridDim.x * FUSED_WAVES;
   float* scr = P.scratch + (int64_t)gw * P.scratch_per_wave;
   constexpr int SLOT = K1 * NTH * 256;  // floats per spilled layer
-  const int L = P.L, act = P.act;
+  const int L = P.L;
 
   for (int64_t tile = gw; tile < P.n_tiles; tile += nw) {
     const int64_t pt = tile * 16 + p;
     const bool valid = pt < P.N;
     const int64_t ptc = valid ? pt : P.N - 1;
     // ---- layer-0 input jet: features 4q + r of (x, unit tangents) --------------------------
+    auto input_jet = [&](f4 (&b)[K1][1]) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = 4 * q + r;
+        b[0][0][r] = (f < P.d_in) ? P.X[ptc * P.d_in + f] : 0.f;
+#pragma unroll
+        for (int c = 1; c < K1; ++c) b[c][0][r] = (f == P.dir_col[c - 1]) ? 1.f : 0.f;
+      }
+    };
     f4 b0[K1][1];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int f = 4 * q + r;
-      b0[0][0][r] = (f < P.d_in) ? P.X[ptc * P.d_in + f] : 0.f;
-#pragma unroll
-      for (int c = 1; c < K1; ++c) b0[c][0][r] = (f == P.dir_col[c - 1]) ? 1.f : 0.f;
-    }
+    input_jet(b0);
     // ---- forward chain ------------------------------------------------------------------------
     f4 a[K1][NTH];
     init_bias<NTH, K1>(P.Bp + b_off_p<WP>(0), a, q);
     gemm_chain<1, NTH, K1>(P.Wp, b0, a, p, q);
-    activate<NTH, K1>(a, act);
+    activate<NTH, K1>(a);
     if (GRAD) spill<NTH, K1>(scr, a, lane);
     for (int l = 1; l < L; ++l) {
       f4 nx[K1][NTH];
       init_bias<NTH, K1>(P.Bp + b_off_p<WP>(l), nx, q);
       gemm_chain<NTH, NTH, K1>(P.Wp + w_off_p<WP>(l), a, nx, p, q);
-      activate<NTH, K1>(nx, act);
+      activate<NTH, K1>(nx);
       if (GRAD) spill<NTH, K1>(scr + l * SLOT, nx, lane);
 #pragma unroll
       for (int c = 0; c < K1; ++c)
@@ -364,39 +440,37 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused(const FusedParams P)
     for (int c = 0; c < K1; ++c) G[c][0] = f4{0.f, 0.f, 0.f, 0.f};
     if (P.loss_kind == 1) {
       if (P.residual_id == PINN_RES_NAVIER_STOKES) {
-        if constexpr (K1 >= 4) residual_tile<ResNavierStokes, K1, GRAD>(P, out, G, sums, valid, false, p, q);
+        if constexpr (K1 >= 4) residual_tile<ResNavierStokes, K1, GRAD>(P, out, G, sums, sm, tb, valid, false, p, q);
       } else if (P.residual_id == PINN_RES_PHYSICS_EQUATION) {
-        if constexpr (K1 >= 3) residual_tile<ResPhysicsEquation, K1, GRAD>(P, out, G, sums, valid, false, p, q);
+        if constexpr (K1 >= 3) residual_tile<ResPhysicsEquation, K1, GRAD>(P, out, G, sums, sm, tb, valid, false, p, q);
       } else {
         if constexpr (K1 >= 3) {
           const bool masked = P.residual_id == PINN_RES_CONTINUITY_ONLY && P.X[ptc * P.d_in + P.xcol] < P.thr;
-          residual_tile<ResContinuity, K1, GRAD>(P, out, G, sums, valid, masked, p, q);
+          residual_tile<ResContinuity, K1, GRAD>(P, out, G, sums, sm, tb, valid, masked, p, q);
         }
       }
     } else if (P.loss_kind == 2) {
+      float gm[1][PINN_MAX_ROLES];
 #pragma unroll
       for (int j = 0; j < PINN_MAX_ROLES; ++j) {
+        gm[0][j] = 0.f;
         if (j < P.n_cols) {
           const float y = gather_out(out[0][0], P.out_col[j], p);
           const float d = P.T[ptc * P.n_cols + j] - y;                  // train.py:141 (true - pred)
           if (valid && q == 0) sums[j] += d * d;
-          if (GRAD) {
-            const float gj = valid ? -2.f * P.scale[j] * d : 0.f;
-#pragma unroll
-            for (int r2 = 0; r2 < 4; ++r2) G[0][0][r2] += (P.out_col[j] == 4 * q + r2) ? gj : 0.f;
-          }
+          if (GRAD) gm[0][j] = -2.f * P.scale[j] * d;
         }
       }
+      if constexpr (GRAD) scatter_adjoint<K1, 1, PINN_MAX_ROLES>(tb, gm, sm, G, valid, p, q);
     }
 
     // ---- reverse sweep ------------------------------------------------------------------------
     if constexpr (GRAD) {
       // output layer L (linear): zbar = G; input = a_L (slot L-1)
       const float* aL = scr + (L - 1) * SLOT;
-      bias_grad<1, K1>(sink, P.PW + b_off_p<WP>(L), G, p, q);
-      weight_grad<1, NTH, K1>(sink, w_off_p<WP>(L), WP, G,
+      weight_grad<1, NTH, K1>(sink, L, w_off_p<WP>(L), P.PW + b_off_p<WP>(L), G,
                               [&](int c, int NT) { return *reinterpret_cast<const f4*>(aL + (c * NTH + NT) * 256 + lane * 4); },
-                              tb, p, q);
+                              tb, lane);
       f4 g[K1][NTH];
 #pragma unroll
       for (int c = 0; c < K1; ++c)
@@ -407,12 +481,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused(const FusedParams P)
         // hidden layer l: output a_{l+1} (slot l), input a_l (slot l-1)
         f4 ao[K1][NTH];
         unspill<NTH, K1>(scr + l * SLOT, ao, lane);
-        activate_adjoint<NTH, K1>(g, ao, act);
-        bias_grad<NTH, K1>(sink, P.PW + b_off_p<WP>(l), g, p, q);
+        activate_adjoint<NTH, K1>(g, ao);
         const float* ai = scr + (l - 1) * SLOT;
-        weight_grad<NTH, NTH, K1>(sink, w_off_p<WP>(l), WP, g,
+        weight_grad<NTH, NTH, K1>(sink, l, w_off_p<WP>(l), P.PW + b_off_p<WP>(l), g,
                                   [&](int c, int NT) { return *reinterpret_cast<const f4*>(ai + (c * NTH + NT) * 256 + lane * 4); },
-                                  tb, p, q);
+                                  tb, lane);
         f4 g2[K1][NTH];
 #pragma unroll
         for (int c = 0; c < K1; ++c)
@@ -427,9 +500,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused(const FusedParams P)
       {  // layer 0: output a_1 (slot 0), input = (x, unit tangents)
         f4 ao[K1][NTH];
         unspill<NTH, K1>(scr, ao, lane);
-        activate_adjoint<NTH, K1>(g, ao, act);
-        bias_grad<NTH, K1>(sink, P.PW + b_off_p<WP>(0), g, p, q);
-        weight_grad<NTH, 1, K1>(sink, 0, 16, g, [&](int c, int) { return b0[c][0]; }, tb, p, q);
+        activate_adjoint<NTH, K1>(g, ao);
+        f4 b1[K1][1];
+        input_jet(b1);   // recomputed rather than kept live across the whole tile
+        weight_grad<NTH, 1, K1>(sink, 0, 0, P.PW + b_off_p<WP>(0), g, [&](int c, int) { return b1[c][0]; }, tb, lane);
       }
     }
   }
@@ -449,7 +523,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused(const FusedParams P)
     for (int w = 0; w < FUSED_WAVES; ++w) v += lsum[w * MAX_SUMS + threadIdx.x];
     P.wg_sums[(int64_t)blockIdx.x * MAX_SUMS + threadIdx.x] = v;
   }
-  if (GRAD && P.acc_lds) {
+  if (GRAD && LDSACC) {
     float* dst = P.wg_grads + (int64_t)blockIdx.x * PP;
     for (int i = threadIdx.x; i < PP; i += FUSED_THREADS) dst[i] = lacc[i];
   }

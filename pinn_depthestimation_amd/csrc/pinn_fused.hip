@@ -37,7 +37,7 @@ int cu_count() {
 constexpr int64_t LDS_LIMIT = 160 * 1024;
 constexpr int NREP = 16;   // replicated global accumulators when the gradient does not fit LDS
 
-int64_t lds_fixed_bytes() { return (int64_t)(FUSED_WAVES * TB_PER_WAVE * TB_FLOATS + FUSED_WAVES * MAX_SUMS) * 4; }
+int64_t lds_fixed_bytes() { return (int64_t)(MAX_LOCKS + FUSED_WAVES * TB_PER_WAVE * TB_FLOATS + FUSED_WAVES * MAX_SUMS) * 4; }
 bool fits_lds(const Geo& g) { return (int64_t)g.PP * 4 + lds_fixed_bytes() <= LDS_LIMIT; }
 
 int grid_for(int64_t n_tiles, bool one_per_cu) {
@@ -131,8 +131,10 @@ __global__ void k_reduce_grads(Net n, int WP, const float* __restrict__ wg, int 
   const int inP = (l == 0) ? 16 : WP;
   const int wo = (l == 0) ? 0 : WP * 16 + (l - 1) * WP * WP;
   int pidx;
-  if (r < (int64_t)in_d * out_d) pidx = wo + (int)(r / in_d) * inP + (int)(r % in_d);
-  else pidx = PW + l * WP + (int)(r - (int64_t)in_d * out_d);
+  if (r < (int64_t)in_d * out_d) {   // fragment-native block layout (fused_kernel.h, GradSink)
+    const int row = (int)(r / in_d), col = (int)(r % in_d), ntn = inP / 16;
+    pidx = wo + (((row >> 4) * ntn + (col >> 4)) * 64 + ((row & 15) >> 2) * 16 + (col & 15)) * 4 + (row & 3);
+  } else pidx = PW + l * WP + (int)(r - (int64_t)in_d * out_d);
   float s = 0.f;
   for (int c = 0; c < copies; ++c) s += wg[(int64_t)c * PP + pidx];
   grad[i] += s;
@@ -213,7 +215,8 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
 }  // namespace
 
 bool fused_supports(const Net& n) {
-  return n.W <= 64 && n.d_in <= 16 && n.d_out <= 16 && n.L >= 1 && n.K1 >= 1 && n.K1 <= 4;
+  if (n.L + 1 > MAX_LOCKS) return false;
+  return n.act == PINN_ACT_TANH && n.W <= 64 && n.d_in <= 16 && n.d_out <= 16 && n.L >= 1 && n.K1 >= 1 && n.K1 <= 4;
 }
 
 int64_t fused_workspace_bytes(const Net& n, int64_t N) {

@@ -4,9 +4,9 @@
 
 namespace pinn {
 
-template <int K1, bool GRAD>
+template <int K1, bool GRAD, bool LDSACC>
 static int launch_one(const FusedParams& P, int grid, size_t lds, hipStream_t s) {
-  auto kern = k_fused<32, K1, GRAD>;
+  auto kern = k_fused<32, K1, GRAD, LDSACC>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e)); return PINN_ERR_LAUNCH; }
@@ -19,16 +19,16 @@ template <>
 int launch_fused<32>(int K1, bool grad, const FusedParams& P, int grid, size_t lds, hipStream_t s) {
   if (!grad) {
     switch (K1) {
-      case 1: return launch_one<1, false>(P, grid, lds, s);
-      case 2: return launch_one<2, false>(P, grid, lds, s);
-      case 3: return launch_one<3, false>(P, grid, lds, s);
-      case 4: return launch_one<4, false>(P, grid, lds, s);
+      case 1: return launch_one<1, false, false>(P, grid, lds, s);
+      case 2: return launch_one<2, false, false>(P, grid, lds, s);
+      case 3: return launch_one<3, false, false>(P, grid, lds, s);
+      case 4: return launch_one<4, false, false>(P, grid, lds, s);
     }
   } else {
     switch (K1) {
-      case 1: return launch_one<1, true>(P, grid, lds, s);
-      case 3: return launch_one<3, true>(P, grid, lds, s);
-      case 4: return launch_one<4, true>(P, grid, lds, s);
+      case 1: return P.acc_lds ? launch_one<1, true, true>(P, grid, lds, s) : launch_one<1, true, false>(P, grid, lds, s);
+      case 3: return P.acc_lds ? launch_one<3, true, true>(P, grid, lds, s) : launch_one<3, true, false>(P, grid, lds, s);
+      case 4: return P.acc_lds ? launch_one<4, true, true>(P, grid, lds, s) : launch_one<4, true, false>(P, grid, lds, s);
     }
   }
   set_error("fused engine: no kernel for K1=%d grad=%d", K1, (int)grad);

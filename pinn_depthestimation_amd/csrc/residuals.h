@@ -143,7 +143,7 @@ __device__ inline float tanh_f32(float x) {
   const float small = fmaf(p * x2, x, x);
   // 1 - 2/(exp(2|x|)+1); exp2 argument clamps naturally (inf -> 1)
   const float e = __expf(2.f * ax);
-  const float big = copysignf(1.f - 2.f * __frcp_rn(e + 1.f), x);
+  const float big = copysignf(fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f), x);   // v_rcp_f32: 1 ulp
   return ax < 0.625f ? small : big;
 }
 
