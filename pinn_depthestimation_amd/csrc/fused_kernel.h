@@ -31,11 +31,14 @@ namespace pinn {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-constexpr int FUSED_WAVES = 8;
+#ifndef PINN_FUSED_WAVES
+#define PINN_FUSED_WAVES 4
+#endif
+constexpr int FUSED_WAVES = PINN_FUSED_WAVES;
 constexpr int FUSED_THREADS = FUSED_WAVES * 64;
 constexpr int TB_STRIDE = 20;                 // floats per row of a transpose block (80 B: conflict-free b128 writes)
 constexpr int TB_FLOATS = 16 * TB_STRIDE;     // one 16x16 block
-constexpr int TB_PER_WAVE = 2;
+constexpr int TB_PER_WAVE = 4;           // two pads for the Zbar transposes, two for the A transposes
 constexpr int MAX_SUMS = 8;
 
 struct FusedParams {
@@ -71,24 +74,53 @@ __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
 template <int WP> __device__ __forceinline__ int w_off_p(int l) { return l == 0 ? 0 : WP * 16 + (l - 1) * WP * WP; }
 template <int WP> __device__ __forceinline__ int b_off_p(int l) { return l * WP; }
 
-// acc[c][MT] += sum_k Wl[16MT + m][k] * bin[c][k]   (Wl row-major, row stride 16*NT_IN)
-template <int NT_IN, int NT_OUT, int K1>
-__device__ __forceinline__ void gemm_chain(const float* __restrict__ Wl, const f4 (&bin)[K1][NT_IN],
-                                           f4 (&acc)[K1][NT_OUT], int m, int kq) {
+// Weight fragments of one layer: w[MT][kt] = Wl[16MT + m][16kt + 4kq .. +3]  (Wl row-major, row
+// stride 16*NT_IN).  Loaded one phase AHEAD of the GEMM that uses them (software prefetch: with
+// one wave per SIMD nothing else hides the L2/MALL latency of these loads).
+template <int NT_IN, int NT_OUT>
+__device__ __forceinline__ void load_w(const float* __restrict__ Wl, f4 (&w)[NT_OUT][NT_IN], int m, int kq) {
   constexpr int LDW = 16 * NT_IN;
 #pragma unroll
-  for (int MT = 0; MT < NT_OUT; ++MT) {
-    f4 a[NT_IN];
+  for (int MT = 0; MT < NT_OUT; ++MT)
 #pragma unroll
     for (int kt = 0; kt < NT_IN; ++kt)
-      a[kt] = *reinterpret_cast<const f4*>(Wl + (16 * MT + m) * LDW + 16 * kt + 4 * kq);
+      w[MT][kt] = *reinterpret_cast<const f4*>(Wl + (16 * MT + m) * LDW + 16 * kt + 4 * kq);
+}
+
+// acc[c][MT] += sum_k W[16MT + m][k] * bin[c][k]
+template <int NT_IN, int NT_OUT, int K1>
+__device__ __forceinline__ void gemm_chain(const f4 (&w)[NT_OUT][NT_IN], const f4 (&bin)[K1][NT_IN],
+                                           f4 (&acc)[K1][NT_OUT]) {
+#pragma unroll
+  for (int MT = 0; MT < NT_OUT; ++MT)
 #pragma unroll
     for (int kt = 0; kt < NT_IN; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int c = 0; c < K1; ++c) acc[c][MT] = mfma4(a[kt][r], bin[c][kt][r], acc[c][MT]);
-  }
+        for (int c = 0; c < K1; ++c) acc[c][MT] = mfma4(w[MT][kt][r], bin[c][kt][r], acc[c][MT]);
+}
+
+template <int NT, int K1>
+__device__ __forceinline__ void zero_tiles(f4 (&v)[K1][NT]) {
+#pragma unroll
+  for (int c = 0; c < K1; ++c)
+#pragma unroll
+    for (int MT = 0; MT < NT; ++MT) v[c][MT] = f4{0.f, 0.f, 0.f, 0.f};
+}
+template <int NT, int K1>
+__device__ __forceinline__ void copy_tiles(f4 (&d)[K1][NT], const f4 (&srcv)[K1][NT]) {
+#pragma unroll
+  for (int c = 0; c < K1; ++c)
+#pragma unroll
+    for (int MT = 0; MT < NT; ++MT) d[c][MT] = srcv[c][MT];
+}
+template <int A, int B>
+__device__ __forceinline__ void copy_w(f4 (&d)[A][B], const f4 (&srcv)[A][B]) {
+#pragma unroll
+  for (int i = 0; i < A; ++i)
+#pragma unroll
+    for (int j = 0; j < B; ++j) d[i][j] = srcv[i][j];
 }
 
 template <int NT, int K1>
@@ -166,12 +198,12 @@ __device__ __forceinline__ float row_sum16(float v) {
 // acc-layout 16x16 block (features x points) -> operand layout of the weight-gradient GEMM:
 // lane (m = lane&15 feature, kq = lane>>4), element s  <-  value(feature m, point 4s + kq)
 __device__ __forceinline__ f4 transpose_block(float* __restrict__ tb, f4 v, int p, int q) {
+  // LDS instructions of one wave execute in program order and the compiler keeps these may-alias
+  // accesses ordered, so the cross-lane exchange needs no barrier.
   *reinterpret_cast<f4*>(tb + p * TB_STRIDE + 4 * q) = v;     // row p holds the 16 features of point p
-  __builtin_amdgcn_wave_barrier();
   f4 o;
 #pragma unroll
   for (int s = 0; s < 4; ++s) o[s] = tb[(4 * s + q) * TB_STRIDE + p];
-  __builtin_amdgcn_wave_barrier();
   return o;
 }
 
@@ -210,6 +242,10 @@ struct GradSink {
       if (lane == 0) __hip_atomic_store(locks + l, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
+  __device__ __forceinline__ void add1(int idx, float v) const {
+    if constexpr (LDSACC) acc[idx] += v;
+    else __hip_atomic_fetch_add(acc + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   __device__ __forceinline__ void add4(int idx, f4 v) const {   // idx: float index, multiple of 4
     if constexpr (LDSACC) {
       f4* ptr = reinterpret_cast<f4*>(acc + idx);
@@ -222,13 +258,14 @@ struct GradSink {
 };
 
 // dW[16MT + 4q + r][16NT + n] += sum_c sum_points Z[c][MT](feature, point) * A[c][NT](feature, point)
-// db[16MT + 4q + r]           += sum_points Z[0][MT]
-// loadA(c, NT) returns the layer-input tile in acc layout.
-template <int MT_N, int NT_N, int K1, class Sink, class LoadA>
+// db[16MT + m]                += sum_points Z[0][MT](feature m, point)
+// A: the layer-input jet in acc layout (registers).
+template <int MT_N, int NT_N, int K1, class Sink>
 __device__ __forceinline__ void weight_grad(const Sink& sink, int layer, int woff, int boff, const f4 (&Z)[K1][MT_N],
-                                            LoadA loadA, float* __restrict__ tb, int lane) {
+                                            const f4 (&A)[K1][NT_N], float* __restrict__ tb, int lane) {
   const int p = lane & 15, q = lane >> 4;
   f4 dw[MT_N][NT_N];
+  float bs[MT_N];
 #pragma unroll
   for (int MT = 0; MT < MT_N; ++MT)
 #pragma unroll
@@ -239,7 +276,16 @@ __device__ __forceinline__ void weight_grad(const Sink& sink, int layer, int wof
 #pragma unroll
     for (int MT = 0; MT < MT_N; ++MT) zt[MT] = transpose_block(tb + (MT & 1) * TB_FLOATS, Z[c][MT], p, q);
 #pragma unroll
-    for (int NT = 0; NT < NT_N; ++NT) at[NT] = transpose_block(tb + (NT & 1) * TB_FLOATS, loadA(c, NT), p, q);
+    for (int NT = 0; NT < NT_N; ++NT) at[NT] = transpose_block(tb + (2 + (NT & 1)) * TB_FLOATS, A[c][NT], p, q);
+    if (c == 0) {   // bias: zt[MT][s] = zbar(feature p, point 4s + q): sum the 4 regs, then the 4 lane groups
+#pragma unroll
+      for (int MT = 0; MT < MT_N; ++MT) {
+        float t = (zt[MT][0] + zt[MT][1]) + (zt[MT][2] + zt[MT][3]);
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        bs[MT] = t;
+      }
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -247,19 +293,14 @@ __device__ __forceinline__ void weight_grad(const Sink& sink, int layer, int wof
 #pragma unroll
         for (int NT = 0; NT < NT_N; ++NT) dw[MT][NT] = mfma4(zt[MT][s], at[NT][s], dw[MT][NT]);
   }
-  f4 bs[MT_N];   // bias partial sums over the tile's 16 points (valid in lanes p == 15)
-#pragma unroll
-  for (int MT = 0; MT < MT_N; ++MT)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bs[MT][r] = row_sum16(Z[0][MT][r]);
   sink.lock(layer, lane);
 #pragma unroll
   for (int MT = 0; MT < MT_N; ++MT)
 #pragma unroll
     for (int NT = 0; NT < NT_N; ++NT) sink.add4(woff + ((MT * NT_N + NT) * 64 + lane) * 4, dw[MT][NT]);
-  if (p == 15) {
+  if (q == 0) {
 #pragma unroll
-    for (int MT = 0; MT < MT_N; ++MT) sink.add4(boff + 16 * MT + 4 * q, bs[MT]);
+    for (int MT = 0; MT < MT_N; ++MT) sink.add1(boff + 16 * MT + p, bs[MT]);
   }
   sink.unlock(layer, lane);
 }
@@ -339,8 +380,24 @@ __device__ __forceinline__ void residual_tile(const FusedParams& P, const f4 (&o
   if constexpr (GRAD) scatter_adjoint<K1, 1 + ND, NR>(tb, g, sm, G, valid, p, q);
 }
 
+// Diagnostic build only (-DPINN_DIAG): s_memtime stamps per phase, printed by wave 0 of block 0.
+// Stamps drain the memory counters, so read the SHARES, never the total (cdna guide §7).
+#ifdef PINN_DIAG
+#define PINN_STAMP(i)                                                                      \
+  do {                                                                                     \
+    unsigned long long t_;                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    diag[i] += t_ - tprev;                                                                 \
+    tprev = t_;                                                                            \
+  } while (0)
+#else
+#define PINN_STAMP(i) do { } while (0)
+#endif
+
 template <int WP, int K1, bool GRAD, bool LDSACC>
-__global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused(const FusedParams P) {
+__global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const FusedParams P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NTH = WP / 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -384,7 +441,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused(const FusedParams P)
   constexpr int SLOT = K1 * NTH * 256;  // floats per spilled layer
   const int L = P.L;
 
+#ifdef PINN_DIAG
+  unsigned long long diag[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#endif
   for (int64_t tile = gw; tile < P.n_tiles; tile += nw) {
+    PINN_STAMP(11);
     const int64_t pt = tile * 16 + p;
     const bool valid = pt < P.N;
     const int64_t ptc = valid ? pt : P.N - 1;
@@ -400,26 +461,45 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused(const FusedParams P)
     };
     f4 b0[K1][1];
     input_jet(b0);
-    // ---- forward chain ------------------------------------------------------------------------
+    // ---- forward chain (weights of layer l+1 are fetched while layer l computes) -------------
+    f4 w0[NTH][1];
+    load_w<1, NTH>(P.Wp, w0, p, q);
+    f4 wh[NTH][NTH];
+    load_w<NTH, NTH>(P.Wp + w_off_p<WP>(L > 1 ? 1 : 0), wh, p, q);      // L == 1: dummy in-bounds read, unused
+    f4 wl[1][NTH];
+    load_w<NTH, 1>(P.Wp + w_off_p<WP>(L), wl, p, q);
     f4 a[K1][NTH];
     init_bias<NTH, K1>(P.Bp + b_off_p<WP>(0), a, q);
-    gemm_chain<1, NTH, K1>(P.Wp, b0, a, p, q);
+    gemm_chain<1, NTH, K1>(w0, b0, a);
+    PINN_STAMP(0);
     activate<NTH, K1>(a);
     if (GRAD) spill<NTH, K1>(scr, a, lane);
+    PINN_STAMP(1);
     for (int l = 1; l < L; ++l) {
+      f4 wn[NTH][NTH];
+      load_w<NTH, NTH>(P.Wp + w_off_p<WP>(l + 1 < L ? l + 1 : l), wn, p, q);   // prefetch (last: redundant, in bounds)
       f4 nx[K1][NTH];
       init_bias<NTH, K1>(P.Bp + b_off_p<WP>(l), nx, q);
-      gemm_chain<NTH, NTH, K1>(P.Wp + w_off_p<WP>(l), a, nx, p, q);
+      gemm_chain<NTH, NTH, K1>(wh, a, nx);
+      PINN_STAMP(0);
       activate<NTH, K1>(nx);
       if (GRAD) spill<NTH, K1>(scr + l * SLOT, nx, lane);
-#pragma unroll
-      for (int c = 0; c < K1; ++c)
-#pragma unroll
-        for (int MT = 0; MT < NTH; ++MT) a[c][MT] = nx[c][MT];
+      PINN_STAMP(1);
+      copy_tiles<NTH, K1>(a, nx);
+      copy_w<NTH, NTH>(wh, wn);
     }
     f4 out[K1][1];
     init_bias<1, K1>(P.Bp + b_off_p<WP>(L), out, q);
-    gemm_chain<NTH, 1, K1>(P.Wp + w_off_p<WP>(L), a, out, p, q);
+    gemm_chain<NTH, 1, K1>(wl, a, out);
+    // reverse-sweep operands whose latency the residual evaluation below hides
+    f4 wtl[NTH][1];
+    f4 wt[NTH][NTH];
+    f4 ai[K1][NTH];
+    if constexpr (GRAD) {
+      load_w<1, NTH>(P.WTp + w_off_p<WP>(L), wtl, p, q);
+      load_w<NTH, NTH>(P.WTp + w_off_p<WP>(L > 1 ? L - 1 : 0), wt, p, q);
+      unspill<NTH, K1>(scr + (L > 1 ? L - 2 : 0) * SLOT, ai, lane);            // a_{L-1}
+    }
 
     // ---- outputs / loss -----------------------------------------------------------------------
     if (P.Y != nullptr && valid) {
@@ -464,49 +544,56 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused(const FusedParams P)
       if constexpr (GRAD) scatter_adjoint<K1, 1, PINN_MAX_ROLES>(tb, gm, sm, G, valid, p, q);
     }
 
+    PINN_STAMP(2);
     // ---- reverse sweep ------------------------------------------------------------------------
+    // Each spilled layer a_l is read ONCE (as the input of layer l's weight gradient, then kept as
+    // the output whose activation adjoint layer l-1 needs), and a_{l-1} / W_{l-1}^T are fetched
+    // while layer l's back-propagation GEMM runs.  `a` still holds a_L from the forward chain.
     if constexpr (GRAD) {
-      // output layer L (linear): zbar = G; input = a_L (slot L-1)
-      const float* aL = scr + (L - 1) * SLOT;
-      weight_grad<1, NTH, K1>(sink, L, w_off_p<WP>(L), P.PW + b_off_p<WP>(L), G,
-                              [&](int c, int NT) { return *reinterpret_cast<const f4*>(aL + (c * NTH + NT) * 256 + lane * 4); },
-                              tb, lane);
+      // output layer L (linear): zbar = G; input = a_L
+      weight_grad<1, NTH, K1>(sink, L, w_off_p<WP>(L), P.PW + b_off_p<WP>(L), G, a, tb, lane);
       f4 g[K1][NTH];
-#pragma unroll
-      for (int c = 0; c < K1; ++c)
-#pragma unroll
-        for (int MT = 0; MT < NTH; ++MT) g[c][MT] = f4{0.f, 0.f, 0.f, 0.f};
-      gemm_chain<1, NTH, K1>(P.WTp + w_off_p<WP>(L), G, g, p, q);
+      zero_tiles<NTH, K1>(g);
+      gemm_chain<1, NTH, K1>(wtl, G, g);
+      f4 ao[K1][NTH];
+      copy_tiles<NTH, K1>(ao, a);
       for (int l = L - 1; l >= 1; --l) {
-        // hidden layer l: output a_{l+1} (slot l), input a_l (slot l-1)
-        f4 ao[K1][NTH];
-        unspill<NTH, K1>(scr + l * SLOT, ao, lane);
+        // hidden layer l: output a_{l+1} (= ao), input a_l (= ai), W_l^T (= wt)
+        PINN_STAMP(3);
         activate_adjoint<NTH, K1>(g, ao);
-        const float* ai = scr + (l - 1) * SLOT;
-        weight_grad<NTH, NTH, K1>(sink, l, w_off_p<WP>(l), P.PW + b_off_p<WP>(l), g,
-                                  [&](int c, int NT) { return *reinterpret_cast<const f4*>(ai + (c * NTH + NT) * 256 + lane * 4); },
-                                  tb, lane);
+        PINN_STAMP(4);
+        weight_grad<NTH, NTH, K1>(sink, l, w_off_p<WP>(l), P.PW + b_off_p<WP>(l), g, ai, tb, lane);
+        PINN_STAMP(5);
+        f4 an[K1][NTH];
+        f4 wtn[NTH][NTH];
+        unspill<NTH, K1>(scr + (l >= 2 ? l - 2 : 0) * SLOT, an, lane);            // a_{l-1} for the next iteration
+        load_w<NTH, NTH>(P.WTp + w_off_p<WP>(l >= 2 ? l - 1 : 1), wtn, p, q);
         f4 g2[K1][NTH];
-#pragma unroll
-        for (int c = 0; c < K1; ++c)
-#pragma unroll
-          for (int MT = 0; MT < NTH; ++MT) g2[c][MT] = f4{0.f, 0.f, 0.f, 0.f};
-        gemm_chain<NTH, NTH, K1>(P.WTp + w_off_p<WP>(l), g, g2, p, q);
-#pragma unroll
-        for (int c = 0; c < K1; ++c)
-#pragma unroll
-          for (int MT = 0; MT < NTH; ++MT) g[c][MT] = g2[c][MT];
+        zero_tiles<NTH, K1>(g2);
+        gemm_chain<NTH, NTH, K1>(wt, g, g2);
+        PINN_STAMP(6);
+        copy_tiles<NTH, K1>(g, g2);
+        copy_tiles<NTH, K1>(ao, ai);
+        copy_tiles<NTH, K1>(ai, an);
+        copy_w<NTH, NTH>(wt, wtn);
       }
-      {  // layer 0: output a_1 (slot 0), input = (x, unit tangents)
-        f4 ao[K1][NTH];
-        unspill<NTH, K1>(scr, ao, lane);
+      {  // layer 0: output a_1 (= ao), input = (x, unit tangents)
         activate_adjoint<NTH, K1>(g, ao);
         f4 b1[K1][1];
         input_jet(b1);   // recomputed rather than kept live across the whole tile
-        weight_grad<NTH, 1, K1>(sink, 0, 0, P.PW + b_off_p<WP>(0), g, [&](int c, int) { return b1[c][0]; }, tb, lane);
+        weight_grad<NTH, 1, K1>(sink, 0, 0, P.PW + b_off_p<WP>(0), g, b1, tb, lane);
       }
     }
+    PINN_STAMP(7);
   }
+#ifdef PINN_DIAG
+  if (blockIdx.x == 0 && threadIdx.x == 0 && GRAD) {
+    unsigned long long tot = 0;
+    for (int i = 0; i < 12; ++i) tot += diag[i];
+    printf("DIAG cycles/wave: fwd_gemm %llu fwd_act+spill %llu out+residual %llu | unspill_wait %llu adjoint %llu wgrad(transp+mfma+flush) %llu bwd_gemm %llu first/last-layer %llu loop-top %llu | total %llu\n",
+           diag[0], diag[1], diag[2], diag[3], diag[4], diag[5], diag[6], diag[7], diag[11], tot);
+  }
+#endif
 
   // ---- per-workgroup reductions ------------------------------------------------------------------
 #pragma unroll
