@@ -1,0 +1,304 @@
+"""CPU-only checks: the C-ABI library loads and exports what include/pinn_hip.h declares, host
+logic (config, DNN parameter storage, graph sniffing, operations, sharding), and the
+data-parallel path under gloo with world_size 2.  No compute call on the library here."""
+import ctypes as C
+import io
+import json
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "compat"))
+
+from pinn_depthestimation_amd import NetDesc, PinnError, ResidualSpec, _lib  # noqa: E402
+from pinn_depthestimation_amd.config import load_config  # noqa: E402
+from pinn_depthestimation_amd.parallel import shard_bounds  # noqa: E402
+
+CMB = {
+    "layers": {"input_features": 2, "hidden_layers": 10, "hidden_width": 10, "output_features": 6,
+               "dropout_rate": 0.0, "init_type": "xavier"},
+    "adam_optimizer": {"max_it": 50000, "learning_rate": 1e-4, "scheduler_step_size": 10000, "scheduler_gamma": 0.8},
+    "lbfgs_optimizer": {"max_it": 50000, "learning_rate": 1, "max_evaluation": 6.25e4, "history_size": 100,
+                        "tolerance_grad": 1e-5, "tolerance_change": 1e-7, "line_search_fn": "strong_wolfe"},
+    "loss": {"weight_h_loss": 1, "weight_eta_mean_loss": 2, "weight_U_loss": 1, "weight_V_loss": 1,
+             "weight_k_loss": 1, "weight_Hrms_loss": 1, "weight_fid_loss": 1, "weight_res_loss": 3},
+    "data_fidelity": {"inputs": ["x", "y"], "outputs": ["h", "U", "V", "eta_mean", "Hrms", "k"], "training_points": 12},
+    "data_residual": {"inputs": {"x": {"requires_grad": ["true"]}, "y": {"requires_grad": ["true"]}},
+                      "outputs": ["h", "U", "V", "eta_mean", "Hrms", "k"]},
+}
+OLD_SCHEMA = {   # shape of config.json: no dropout_rate/init_type, float iteration counts, dict outputs
+    "layers": {"input_features": 5, "hidden_layers": 100, "hidden_width": 20, "output_features": 4},
+    "adam_optimizer": {"max_it": 0, "learning_rate": 1e-4, "scheduler_step_size": 10000, "scheduler_gamma": 0.8},
+    "lbfgs_optimizer": {"max_it": 5.00e4, "learning_rate": 1, "max_evaluation": 6.25e4, "history_size": 100,
+                        "tolerance_grad": 1e-5, "tolerance_change": 1e-7, "line_search_fn": "strong_wolfe"},
+    "loss": {"weight_fid_loss": 1, "weight_res_loss": 100000},
+    "data_fidelity": {"dir": "x.csv", "inputs": ["t", "x", "y", "u", "v"], "outputs": ["h", "z", "u", "v"]},
+    "data_residual": {"inputs": {"t": {"file": "t", "requires_grad": ["true"]}, "x": {"file": "X", "requires_grad": ["true"]},
+                                 "y": {"file": "Y", "requires_grad": ["true"]}, "u": {"file": "u", "requires_grad": ["false"]},
+                                 "v": {"file": "v", "requires_grad": ["false"]}},
+                      "outputs": {"h": {"file": "dep.out"}, "z": {"file": "eta"}, "u": {"file": "u"}, "v": {"file": "v"}}},
+}
+NEWMETHOD = {
+    "layers": {"input_features": 2, "hidden_layers": 100, "hidden_width": 20, "output_features": 3,
+               "dropout_rate": 0.0, "init_type": "xavier"},
+    "adam_optimizer": {"max_it": 50000, "learning_rate": 1e-4, "scheduler_step_size": 10000, "scheduler_gamma": 0.8},
+    "lbfgs_optimizer": {"max_it": 50000, "learning_rate": 1, "max_evaluation": 6.25e4, "history_size": 100,
+                        "tolerance_grad": 1e-5, "tolerance_change": 1e-7, "line_search_fn": "strong_wolfe"},
+    "loss": {"weight_fid_loss": 1, "weight_res_loss": 1},
+    "data": {"inputs": {"x": {"requires_grad": ["true"]}, "y": {"requires_grad": ["true"]}},
+             "trues": ["U", "V"], "unknowns": ["h"]},
+}
+
+
+# ---- C-ABI -------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "pinn_hip.h")).read()
+    declared = set(re.findall(r"\b(pinn_[a-z_]+)\s*\(", header))
+    assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.pinn_version() == 1
+
+
+def test_param_count_and_error_reporting_without_gpu():
+    lib = _lib.load()
+    d = NetDesc(3, 4, 8, 64, (0, 1, 2))
+    cnt = C.c_int64()
+    assert lib.pinn_param_count(C.byref(d.c_struct()), C.byref(cnt)) == 0
+    assert cnt.value == d.n_params == 29636
+    assert NetDesc(2, 6, 10, 10, (0, 1)).n_params == 1086
+    bad = d.with_(activation=7).c_struct()
+    assert lib.pinn_param_count(C.byref(bad), C.byref(cnt)) == -1
+    assert b"invalid activation" in lib.pinn_last_error()
+    need = C.c_int64()
+    assert lib.pinn_query_workspace(C.byref(d.c_struct()), 1 << 20, C.byref(need)) == 0 and need.value > 0
+    big = NetDesc(3, 4, 12, 256, (0, 1, 2))                        # BASELINE configs[3]: generic engine only
+    assert lib.pinn_query_workspace(C.byref(big.with_(engine=_lib.ENGINE_FUSED).c_struct()), 1024, C.byref(need)) == -2
+    assert lib.pinn_query_workspace(C.byref(big.c_struct()), 1024, C.byref(need)) == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(PinnError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_residual_spec_role_mapping():
+    s = ResidualSpec.from_names("Navier_Stokes", ("t", "x", "y", "u", "v"), (0, 1, 2), ("h", "z", "u", "v"))
+    assert s.out_col == (0, 1, 2, 3) and s.dir_of == (0, 1, 2) and s.n_terms == 3
+    s = ResidualSpec.from_names("continuity_only", ("x", "y"), (0, 1), ("U", "V", "h"))
+    assert s.out_col == (2, 0, 1) and s.n_terms == 3 and s.threshold == 25.5 and s.anchor == 0.75
+    with pytest.raises(PinnError, match="requires_grad"):
+        ResidualSpec.from_names("Navier_Stokes", ("t", "x", "y"), (1, 2), ("h", "z", "u", "v"))
+    with pytest.raises(PinnError, match="needs output"):
+        ResidualSpec.from_names("physics_equation", ("x", "y"), (0, 1), ("h", "U", "V"))
+
+
+# ---- config --------------------------------------------------------------------------------------
+def test_config_schemas():
+    c = load_config(CMB)
+    assert c.layers == [2] + [10] * 10 + [6] and c.grad_cols == (0, 1) and c.variant == "train"
+    assert c.default_residual() == "physics_equation" and c.lbfgs["max_evaluation"] == 62500
+    assert c.output_weight("eta_mean") == 2 and c.weight_res == 3
+    o = load_config(OLD_SCHEMA)
+    assert o.dropout_rate == 0.0 and o.init_type == "xavier"          # defaults where train.py:59,62 would KeyError
+    assert o.lbfgs["max_it"] == 50000 and isinstance(o.lbfgs["max_it"], int)
+    assert o.residual_inputs == ["t", "x", "y", "u", "v"] and o.grad_cols == (0, 1, 2)
+    assert o.residual_outputs == ["h", "z", "u", "v"] and o.default_residual() == "Navier_Stokes"
+    n = load_config(NEWMETHOD)
+    assert n.variant == "newmethod" and n.residual_outputs == ["U", "V", "h"] and n.fidelity_outputs == ["U", "V"]
+    assert n.default_residual() == "continuity_only"
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree only exists in the build container")
+def test_reference_config_files_parse_verbatim():
+    for f, nl in (("config_CMB.json", 12), ("config_CMB_h.json", 102), ("config.json", 102), ("config_txyz.json", 22)):
+        c = load_config(os.path.join("/root/reference", f))
+        assert len(c.layers) == nl and len(c.grad_cols) >= 2
+
+
+# ---- DNN ---------------------------------------------------------------------------------------------
+def test_dnn_is_dropin_module():
+    import dnn
+    torch.manual_seed(0)
+    m = dnn.DNN([3] + [64] * 8 + [4], 0.0, "xavier")
+    sd = m.state_dict()
+    assert list(sd) == [f"layers.layer_{i}.{k}" for i in range(9) for k in ("weight", "bias")]
+    assert sd["layers.layer_1.weight"].shape == (64, 64)
+    bound = (6.0 / 128) ** 0.5
+    assert float(sd["layers.layer_1.weight"].abs().max()) <= bound                 # xavier_uniform_, gain 1
+    assert all(float(sd[f"layers.layer_{i}.bias"].abs().sum()) == 0 for i in range(8))   # dnn.py:33,51-52
+    assert float(sd["layers.layer_8.bias"].abs().sum()) > 0                       # last layer keeps the default
+    assert isinstance(m.activation, torch.nn.Tanh) and m.layers.activation_0 is m.layers.activation_5
+    k = dnn.DNN([2, 8, 8, 1], 0.0, "kaiming")
+    assert isinstance(k.activation, torch.nn.LeakyReLU) and k.activation.negative_slope == 0.01
+    with pytest.raises(ValueError, match="Invalid init_type: he. Use 'kaiming' or 'xavier'."):
+        dnn.DNN([2, 4, 1], 0.0, "he")
+
+
+def test_flat_parameter_storage_tracks_optimizers_and_moves():
+    import dnn
+    m = dnn.DNN([2, 5, 5, 3], 0.0, "xavier")
+    flat = m.flat_params()
+    assert flat.numel() == sum(p.numel() for p in m.parameters()) and m._aliased()
+    ref = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    assert torch.equal(flat, ref)
+    opt = torch.optim.Adam(m.parameters(), lr=0.1)
+    for p in m.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    assert torch.equal(m.flat_params(), torch.cat([p.detach().reshape(-1) for p in m.parameters()]))
+    assert not torch.equal(m.flat_params(), ref)
+    sd = {k: torch.full_like(v, 0.5) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    assert m._aliased() and float(m.flat_params().min()) == 0.5
+    m.double(); m.float()                               # _apply breaks the aliasing; flat_params() restores it
+    assert m.flat_params().dtype == torch.float32 and m._aliased()
+    buf = io.BytesIO()
+    torch.save(m, buf); buf.seek(0)                     # whole-module pickle, as train.py:179 does
+    m2 = torch.load(buf, weights_only=False)
+    assert type(m2).__name__ == "DNN" and torch.equal(m2.flat_params(), m.flat_params())
+
+
+def test_forward_refuses_cpu_and_dropout():
+    import dnn
+    m = dnn.DNN([2, 4, 4, 1], 0.5, "xavier")
+    m.train()
+    with pytest.raises(NotImplementedError, match="Dropout"):
+        m(torch.zeros(3, 2))
+    m.eval()
+    with pytest.raises(PinnError, match="no CPU path"):
+        m(torch.zeros(3, 2))
+
+
+# ---- graph sniffing ------------------------------------------------------------------------------------
+def test_sniffing_of_differentiated_columns():
+    from pinn_depthestimation_amd.autograd import JetHandle, JetTensor, _sniff_sources
+    import dnn
+    m = dnn.DNN([3, 4, 4, 2], 0.0, "xavier")
+    N = 6
+    t = torch.tensor(np.random.rand(N, 1), requires_grad=True).float()     # non-leaf, as train.py:88
+    x = torch.rand(N, 1)                                                   # requires_grad "false"
+    y = torch.rand(N, 1, requires_grad=True)                               # leaf
+    X = torch.cat([t, x, y], dim=-1)
+    cols, src = _sniff_sources(m, X)
+    assert cols == (0, 2) and src[0][0] == "node" and src[1][0] == "leaf"
+    h = JetHandle(m, X.detach(), X, cols, src)
+    assert h.direction_of(t) == 0 and h.direction_of(y) == 1 and h.direction_of(x) is None
+    Y = JetTensor.wrap(torch.rand(N, 2), h, (0, 1))
+    c1 = Y[:, 1:2]
+    assert isinstance(c1, JetTensor) and c1._pinn_cols == (1,) and c1._pinn_handle is h
+    assert not isinstance(c1 * 2.0, JetTensor) and not isinstance(Y[0:3, 0:1], JetTensor)
+    m.set_grad_columns([0, 2])
+    leaf = torch.rand(N, 3, requires_grad=True)
+    assert _sniff_sources(m, leaf)[0] == (0, 2)
+    m.set_grad_columns(None)
+    with pytest.raises(PinnError, match="cannot tell which input columns"):
+        _sniff_sources(m, leaf * 1.0)
+
+
+# ---- operations -----------------------------------------------------------------------------------------
+def test_operations_match_reference_semantics():
+    import operations as op
+    a = np.array([25.0, 29.0, 33.0])
+    n = op.normalize(a, 25.0, 33.0)
+    assert np.allclose(n, [-1, 0, 1]) and np.allclose(op.denormalize(n, 25.0, 33.0), a)
+    assert np.all(op.normalize(a, 2.0, 2.0) == 0)
+    cfg = {"data_test": {"x_min": 25.0, "x_max": 33.0, "y_min": -13.0, "y_max": 13.0}}
+    data = {"x": a, "y": a, "U": np.array([1.0, np.nan, -2.0])}
+    assert op.get_min_max(data, "x", cfg) == {"x": (25.0, 33.0)}                 # operations.py:16 signature
+    mm = op.get_min_max(data, cfg)                                               # train.py:228 call form
+    assert mm["y"] == (-13.0, 13.0) and mm["U"] == (-2.0, 1.0)
+
+
+def test_shard_bounds_partition():
+    for n in (0, 1, 7, 243, 1 << 20):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_bench_cpu_count_is_bounded():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert 1 <= bench.usable_cpus() <= 32
+
+
+# ---- data parallel under gloo ----------------------------------------------------------------------------------
+def _oracle_evaluator(cfg_layers, spec_name, in_roles, out_roles, grad_cols, fid_cols):
+    """Stand-in for HipEvaluator in CPU tests: same contract, arithmetic by the oracle."""
+    from oracle import pinn_oracle as O
+
+    def ev(theta, Xf, Tf, fid_scale, Xr, res_scale, grad, fid_sums, res_sums):
+        p = [q.clone().requires_grad_(True) for q in O.unflatten(theta.detach(), cfg_layers)]
+        obj = 0
+        if Xf is not None and Xf.shape[0] > 0:
+            Y = O.mlp_forward(p, Xf)
+            s = torch.stack([((Tf[:, j] - Y[:, c]) ** 2).sum() for j, c in enumerate(fid_cols)])
+            fid_sums.copy_(s.detach()); obj = obj + (s * fid_scale).sum()
+        else:
+            fid_sums.zero_()
+        if Xr is not None and Xr.shape[0] > 0:
+            cols = O.split_columns(Xr, grad_cols)
+            Y = O.mlp_forward(p, torch.cat(cols, -1))
+            f = O.navier_stokes_fields(*[cols[i] for i in in_roles], *[Y[:, o:o + 1] for o in out_roles])
+            s = torch.stack([(t ** 2).sum() for t in f])
+            res_sums.copy_(s.detach()); obj = obj + (s * res_scale).sum()
+        else:
+            res_sums.zero_()
+        grad.add_(O.flat_grad(obj, p))
+    return ev
+
+
+def _dp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    tr = _make_trainer()
+    losses = [float(tr.adam_step()) for _ in range(3)]
+    if rank == 0:
+        torch.save({"losses": losses, "theta": tr.dnn.flat_params().clone(), "n_local": tr.Xr.shape[0]}, out)
+    dist.destroy_process_group()
+
+
+def _make_trainer():
+    import dnn
+    from pinn_depthestimation_amd.parallel import Reducer
+    from pinn_depthestimation_amd.trainer import PINN
+    cfg = {"layers": {"input_features": 3, "hidden_layers": 2, "hidden_width": 8, "output_features": 4},
+           "adam_optimizer": {"max_it": 3, "learning_rate": 1e-3, "scheduler_step_size": 2, "scheduler_gamma": 0.5},
+           "lbfgs_optimizer": {"max_it": 0}, "loss": {"weight_fid_loss": 2, "weight_res_loss": 1},
+           "data_fidelity": {"inputs": ["t", "x", "y"], "outputs": ["h", "z"]},
+           "data_residual": {"inputs": {k: {"requires_grad": ["true"]} for k in "txy"}, "outputs": ["h", "z", "u", "v"]}}
+    g = torch.Generator().manual_seed(5)
+    Xf, Tf = torch.rand(9, 3, generator=g), torch.rand(9, 2, generator=g)
+    Xr = torch.rand(101, 3, generator=g) * 2 - 1
+    torch.manual_seed(7)
+    model = dnn.DNN([3, 8, 8, 4], 0.0, "xavier")
+    ev = _oracle_evaluator([3, 8, 8, 4], "Navier_Stokes", [0, 1, 2], [0, 1, 2, 3], (0, 1, 2), [0, 1])
+    return PINN(Xf.numpy(), Tf.numpy(), Xr.numpy(), cfg, device="cpu", evaluator=ev, dnn=model,
+                reducer=Reducer(), checkpoint_every=0)
+
+
+def test_data_parallel_world2_matches_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    single = _make_trainer()
+    ref_losses = [float(single.adam_step()) for _ in range(3)]
+    out = str(tmp_path / "r0.pt")
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["n_local"] == 51                                   # 101 points -> 51 + 50
+    assert np.allclose(got["losses"], ref_losses, rtol=2e-6)
+    assert torch.allclose(got["theta"], single.dnn.flat_params(), rtol=0, atol=2e-6)
+    assert ref_losses[2] != ref_losses[0]
