@@ -380,41 +380,6 @@ __device__ __forceinline__ void residual_tile(const FusedParams& P, const f4 (&o
   if constexpr (GRAD) scatter_adjoint<K1, 1 + ND, NR>(tb, g, sm, G, valid, p, q);
 }
 
-// One hidden layer of the forward chain.  Reads (ain, win); prefetches the weights of layer
-// `l_next` into wnext; leaves the activated jet in aout (and spills it when a gradient is wanted).
-// Called with its two register sets swapped on alternate layers (ping-pong), so the runtime layer
-// loop carries no register copies.
-template <int WP, int NTH, int K1, bool GRAD>
-__device__ __forceinline__ void fwd_hidden_layer(const FusedParams& P, int l, int l_next, const f4 (&ain)[K1][NTH],
-                                                 const f4 (&win)[NTH][NTH], f4 (&aout)[K1][NTH], f4 (&wnext)[NTH][NTH],
-                                                 float* __restrict__ slot, int lane) {
-  const int p = lane & 15, q = lane >> 4;
-  load_w<NTH, NTH>(P.Wp + w_off_p<WP>(l_next), wnext, p, q);
-  init_bias<NTH, K1>(P.Bp + b_off_p<WP>(l), aout, q);
-  gemm_chain<NTH, NTH, K1>(win, ain, aout);
-  activate<NTH, K1>(aout);
-  if (GRAD) spill<NTH, K1>(slot, aout, lane);
-}
-
-// One hidden layer l of the reverse sweep.  In: gin = adjoint of a_{l+1}, aout_act = a_{l+1},
-// ain_act = a_l, wt = W_l^T.  Out: gout = adjoint of a_l; aout_act is overwritten with a_{l-1}
-// (prefetched from `next_slot`) and wtn with W_{l-1}^T, so the caller's next layer runs with the
-// roles of (aout_act, ain_act), (gin, gout), (wt, wtn) swapped.
-template <int WP, int NTH, int K1, class Sink>
-__device__ __forceinline__ void bwd_hidden_layer(const FusedParams& P, const Sink& sink, int l, int l_wnext,
-                                                 f4 (&gin)[K1][NTH], f4 (&aout_act)[K1][NTH],
-                                                 const f4 (&ain_act)[K1][NTH], const f4 (&wt)[NTH][NTH],
-                                                 f4 (&gout)[K1][NTH], f4 (&wtn)[NTH][NTH],
-                                                 const float* __restrict__ next_slot, float* __restrict__ tb, int lane) {
-  const int p = lane & 15, q = lane >> 4;
-  activate_adjoint<NTH, K1>(gin, aout_act);
-  weight_grad<NTH, NTH, K1>(sink, l, w_off_p<WP>(l), P.PW + b_off_p<WP>(l), gin, ain_act, tb, lane);
-  unspill<NTH, K1>(next_slot, aout_act, lane);                 // a_{l-1}: lands while the GEMM below runs
-  load_w<NTH, NTH>(P.WTp + w_off_p<WP>(l_wnext), wtn, p, q);
-  zero_tiles<NTH, K1>(gout);
-  gemm_chain<NTH, NTH, K1>(wt, gin, gout);
-}
-
 // Diagnostic build only (-DPINN_DIAG): s_memtime stamps per phase, printed by wave 0 of block 0.
 // Stamps drain the memory counters, so read the SHARES, never the total (cdna guide §7).
 #ifdef PINN_DIAG
@@ -510,20 +475,19 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
     activate<NTH, K1>(a);
     if (GRAD) spill<NTH, K1>(scr, a, lane);
     PINN_STAMP(1);
-    {
-      f4 nx[K1][NTH];
+    for (int l = 1; l < L; ++l) {
       f4 wn[NTH][NTH];
-      int l = 1;
-      for (; l + 1 < L; l += 2) {      // two layers per trip, register sets swapped
-        fwd_hidden_layer<WP, NTH, K1, GRAD>(P, l, l + 1, a, wh, nx, wn, scr + l * SLOT, lane);
-        fwd_hidden_layer<WP, NTH, K1, GRAD>(P, l + 1, l + 2 < L ? l + 2 : l + 1, nx, wn, a, wh, scr + (l + 1) * SLOT, lane);
-      }
-      if (l < L) {
-        fwd_hidden_layer<WP, NTH, K1, GRAD>(P, l, l, a, wh, nx, wn, scr + l * SLOT, lane);
-        copy_tiles<NTH, K1>(a, nx);     // once per tile
-      }
+      load_w<NTH, NTH>(P.Wp + w_off_p<WP>(l + 1 < L ? l + 1 : l), wn, p, q);   // prefetch (last: redundant, in bounds)
+      f4 nx[K1][NTH];
+      init_bias<NTH, K1>(P.Bp + b_off_p<WP>(l), nx, q);
+      gemm_chain<NTH, NTH, K1>(wh, a, nx);
+      PINN_STAMP(0);
+      activate<NTH, K1>(nx);
+      if (GRAD) spill<NTH, K1>(scr + l * SLOT, nx, lane);
+      PINN_STAMP(1);
+      copy_tiles<NTH, K1>(a, nx);
+      copy_w<NTH, NTH>(wh, wn);
     }
-    PINN_STAMP(0);
     f4 out[K1][1];
     init_bias<1, K1>(P.Bp + b_off_p<WP>(L), out, q);
     gemm_chain<NTH, 1, K1>(wl, a, out);
@@ -594,23 +558,23 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
       f4 ao[K1][NTH];
       copy_tiles<NTH, K1>(ao, a);
       for (int l = L - 1; l >= 1; --l) {
-        // hidden layer l: output a_{l+1} (= ao), input a_l (= ai), W_l^T (= wt).  (A two-layer
-        // ping-pong of these register sets was measured slower: 6 live 64-register sets push
-        // more AGPR<->VGPR traffic than the copies below cost.)
-        f4 g2[K1][NTH];
-        f4 wtn[NTH][NTH];
+        // hidden layer l: output a_{l+1} (= ao), input a_l (= ai), W_l^T (= wt)
         PINN_STAMP(3);
-        bwd_hidden_layer<WP, NTH, K1>(P, sink, l, l >= 2 ? l - 1 : 1, g, ao, ai, wt, g2, wtn,
-                                      scr + (l >= 2 ? l - 2 : 0) * SLOT, tb, lane);
+        activate_adjoint<NTH, K1>(g, ao);
+        PINN_STAMP(4);
+        weight_grad<NTH, NTH, K1>(sink, l, w_off_p<WP>(l), P.PW + b_off_p<WP>(l), g, ai, tb, lane);
+        PINN_STAMP(5);
+        f4 an[K1][NTH];
+        f4 wtn[NTH][NTH];
+        unspill<NTH, K1>(scr + (l >= 2 ? l - 2 : 0) * SLOT, an, lane);            // a_{l-1} for the next iteration
+        load_w<NTH, NTH>(P.WTp + w_off_p<WP>(l >= 2 ? l - 1 : 1), wtn, p, q);
+        f4 g2[K1][NTH];
+        zero_tiles<NTH, K1>(g2);
+        gemm_chain<NTH, NTH, K1>(wt, g, g2);
         PINN_STAMP(6);
-        // after the call: ao holds a_{l-1} (prefetched), ai holds a_l
         copy_tiles<NTH, K1>(g, g2);
-        {
-          f4 t[K1][NTH];
-          copy_tiles<NTH, K1>(t, ao);
-          copy_tiles<NTH, K1>(ao, ai);
-          copy_tiles<NTH, K1>(ai, t);
-        }
+        copy_tiles<NTH, K1>(ao, ai);
+        copy_tiles<NTH, K1>(ai, an);
         copy_w<NTH, NTH>(wt, wtn);
       }
       {  // layer 0: output a_1 (= ao), input = (x, unit tangents)
