@@ -58,7 +58,8 @@ class PINN:
     def __init__(self, fidelity_input, fidelity_true, residual_input, config, residual: Optional[str] = None,
                  device="cuda", log_dir: Optional[str] = None, log_every: int = 1, checkpoint_every: int = 1000,
                  reducer: Optional[Reducer] = None, evaluator: Optional[Callable] = None,
-                 dnn: Optional[DNN] = None, engine: int = 0):
+                 dnn: Optional[DNN] = None, engine: int = 0, mat_dump_iter: Optional[int] = None,
+                 mat_dump_path: str = "data_at50k.mat"):
         cfg = config if isinstance(config, PinnConfig) else load_config(config)
         self.config, self.device = cfg, torch.device(device)
         self.reducer = reducer or Reducer()
@@ -102,6 +103,7 @@ class PINN:
         self.evaluator = evaluator or HipEvaluator(cfg.layers, cfg.init_type, cfg.grad_cols, self.spec,
                                                    self.fid_cols, dev, engine)
 
+        self.mat_dump_iter, self.mat_dump_path = mat_dump_iter, mat_dump_path
         self.iter = 0                                                      # train.py:73
         self.adam_maxit = cfg.adam["max_it"]
         self.log_dir, self.log_every, self.checkpoint_every = log_dir, max(int(log_every), 1), checkpoint_every
@@ -132,6 +134,8 @@ class PINN:
     def loss_func(self) -> torch.Tensor:
         """Total loss (0-dim device tensor); self.grad holds d loss / d theta afterwards."""
         self.theta = self.dnn.flat_params()
+        if self.mat_dump_iter is not None and self.iter == self.mat_dump_iter:
+            self.dump_predictions(self.mat_dump_path)                      # train_newmethod.py:141-153
         self.buf.zero_()
         self.evaluator(self.theta, self.Xf, self.Tf, self._fid_scale, self.Xr, self._res_scale, self.grad,
                        self._fid_sums, self._res_sums)
@@ -162,6 +166,16 @@ class PINN:
                 self._log_fh.write("Epoch, Fidelity Loss, Residual Loss, Total Loss\n")       # train.py:167
         self._log_fh.write(f"{self.iter}, {fid:.5e}, {res:.5e}, {tot:.5e}\n")                 # train.py:170
         self._log_fh.flush()
+
+    def dump_predictions(self, path: str):
+        """savemat of pred_<key> (N,1) float32 for every network output on the (local) residual
+        points — the file format of the reference's data_at50k.mat (train_newmethod.py:141-153)."""
+        from scipy.io import savemat
+        Y = self.predict(self.Xr).detach().cpu().numpy().astype(np.float32)
+        names = self.config.residual_outputs
+        savemat(path, {f"pred_{k}": Y[:, i:i + 1] for i, k in enumerate(names)})
+        if self.reducer.rank == 0:
+            print(f"Data saved to {path} after {self.iter} iterations.")
 
     def save_checkpoint(self, name: str):
         if self.log_dir is None or self.reducer.rank != 0:

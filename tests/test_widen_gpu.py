@@ -1,0 +1,94 @@
+"""GPU tests of the rows either side of the hot path: grid inference with the
+physics-only L-BFGS fine-tune (test.py), the SciPy L-BFGS-B stage (BASELINE configs[4]), the
+.mat prediction dump (train_newmethod.py:141-153) and checkpoint round trips."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "compat"))
+
+from oracle import pinn_oracle as O  # noqa: E402
+from tests.golden_util import layers_of, load, rel_l2, state_dict  # noqa: E402
+from tests.test_dropin_gpu import CMB, ns_config  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def test_grid_inference_and_physics_only_finetune():
+    """test.py on config_CMB.json's 81 x 261 grid (21 141 points), 2 -> 8x64 -> 6, physics_equation."""
+    import dnn
+    from pinn_depthestimation_amd.inference import Tester
+    z = load("g4_pe_8x64_conditioned.npz")
+    sd = state_dict(z)
+    cfg = dict(CMB)
+    cfg["layers"] = dict(CMB["layers"], hidden_layers=8, hidden_width=64)
+    cfg["data_test"] = {"inputs": CMB["data_residual"]["inputs"], "outputs": CMB["data_residual"]["outputs"],
+                        "nx": 81, "ny": 261, "x_min": 25.0, "x_max": 33.0, "y_min": -13.0, "y_max": 13.0}
+    model = dnn.DNN(layers_of(sd), 0.0, "xavier")
+    model.load_state_dict(sd)
+    xs, ys = np.meshgrid(np.linspace(-1, 1, 81), np.linspace(-1, 1, 261))
+    grid = np.hstack([xs.reshape(-1, 1), ys.reshape(-1, 1)]).astype(np.float32)
+    t = Tester(model, cfg)
+    pred0 = t.test(grid, input_min_max={"x": (25.0, 33.0), "y": (-13.0, 13.0)}, perform_optimization=False)
+    params = O.params_from_state_dict(sd)
+    ref0 = O.mlp_forward([p.double() for p in params], torch.from_numpy(grid).double()).numpy()
+    assert pred0.shape == (21141, 6) and np.abs(pred0 - ref0).max() < 2e-6
+    assert t.plot_pred_h.shape == (261, 81) and np.allclose(t.plot_input_x[0, :], np.linspace(25, 33, 81), atol=1e-5)
+    # one LBFGS.step (max_iter=1, max_eval=2, history 10) on the residual alone, test.py:44-54,92-104
+    pred1 = t.test(grid, perform_optimization=True)
+    Xg = torch.from_numpy(grid)
+    loss_fn = lambda p: O.residual_loss(p, Xg, "physics_equation", [0, 1], [0, 1, 2, 3, 4, 5], (0, 1))
+    losses, p_end = O.lbfgs_trajectory(params, loss_fn, max_iter=1, max_eval=2, history_size=10)
+    ref1 = O.mlp_forward(p_end, Xg).numpy()
+    assert abs(float(t.last_loss) - losses[-1]) / losses[-1] < 1e-3
+    assert np.abs(pred1 - ref1).max() < 1e-4 and np.abs(pred1 - pred0).max() > 1e-6
+
+
+def test_scipy_lbfgsb_stage_after_adam_warm_start():
+    """BASELINE configs[4]: full-batch closure under scipy.optimize L-BFGS-B after the Adam stage."""
+    import dnn
+    from pinn_depthestimation_amd.lbfgsb import LBFGSBOptimizer
+    from pinn_depthestimation_amd.trainer import pinn
+    z7, z8 = load("g7_adam_ns_8x64.npz"), load("g8_lbfgs_ns_8x64.npz")
+    model = dnn.DNN([3] + [64] * 8 + [4], 0.0, "xavier")
+    model.load_state_dict(state_dict(z7, "sd_end/"))
+    tr = pinn(None, None, z7["X"][:2000], ns_config(0), dnn=model, log_every=10 ** 9, checkpoint_every=0)
+    opt = LBFGSBOptimizer(tr, {"maxiter": 40, "maxfun": 60})
+    res = opt.minimize()
+    assert abs(opt.losses[0] - z8["losses"][0]) / z8["losses"][0] < 5e-6      # same start as the torch-LBFGS golden
+    assert res.fun < 0.1 * opt.losses[0] and res.nit >= 10
+    assert abs(float(tr.loss_func()) - res.fun) / res.fun < 1e-4             # best point left in the network
+
+
+def test_mat_dump_and_checkpoint_formats(tmp_path):
+    import dnn
+    from scipy.io import loadmat
+    from pinn_depthestimation_amd.trainer import pinn
+    z = load("g9_newmethod_at50k.npz")
+    sd = state_dict(z, "8x64/sd/")
+    cfg = {"layers": {"input_features": 2, "hidden_layers": 8, "hidden_width": 64, "output_features": 3,
+                      "dropout_rate": 0.0, "init_type": "xavier"},
+           "adam_optimizer": {"max_it": 3, "learning_rate": 1e-4, "scheduler_step_size": 10000, "scheduler_gamma": 0.8},
+           "lbfgs_optimizer": {"max_it": 0}, "loss": {"weight_fid_loss": 1, "weight_res_loss": 1},
+           "data": {"inputs": {"x": {"requires_grad": ["true"]}, "y": {"requires_grad": ["true"]}},
+                    "trues": ["U", "V"], "unknowns": ["h"]}}
+    model = dnn.DNN(layers_of(sd), 0.0, "xavier")
+    model.load_state_dict(sd)
+    T = np.concatenate([z["U"], z["V"]], 1)
+    mat = str(tmp_path / "data_at2.mat")
+    tr = pinn(z["X"], T, z["X"], cfg, dnn=model, log_dir=str(tmp_path), log_every=1, checkpoint_every=2,
+              mat_dump_iter=2, mat_dump_path=mat)
+    tr.train()
+    m = loadmat(mat)
+    for k in ("pred_U", "pred_V", "pred_h"):                                  # data_at50k.mat's variables
+        assert m[k].shape == (12514, 1) and m[k].dtype == np.float32
+    whole = torch.load(tmp_path / "model_2.pth", weights_only=False)          # torch.save(self.dnn), train.py:179
+    sd2 = torch.load(tmp_path / "model_2.state.pth", weights_only=True)
+    assert type(whole).__name__ == "DNN" and list(sd2) == list(sd)
+    assert torch.equal(whole.state_dict()["layers.layer_3.weight"].cpu(), sd2["layers.layer_3.weight"].cpu())
+    rows = open(tmp_path / "log.txt").read().splitlines()
+    assert rows[0].startswith("Epoch, Fidelity Loss") and len(rows) == 4 and rows[3].startswith("3, ")
