@@ -23,6 +23,14 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 FLOP_PER_POINT = 695_424          # 6*M*(1+k), M = 29 120, k = 3 (3->8x64->4)
+
+# name: (d_in, d_out, hidden, width, grad_cols, residual, input names, output names, flop/point = 6*M*(1+k))
+WORKLOADS = {
+    "ns8x64": (3, 4, 8, 64, (0, 1, 2), "Navier_Stokes", ("t", "x", "y"), ("h", "z", "u", "v"), 695_424),          # BASELINE configs[1]
+    "pe8x64": (2, 6, 8, 64, (0, 1), "physics_equation", ("x", "y"), ("h", "U", "V", "eta_mean", "Hrms", "k"), 523_776),  # configs[2], 8x64
+    "pe10x10": (2, 6, 10, 10, (0, 1), "physics_equation", ("x", "y"), ("h", "U", "V", "eta_mean", "Hrms", "k"), 17_400),  # configs[2] as written
+    "co100x20": (2, 3, 100, 20, (0, 1), "continuity_ftemp", ("x", "y"), ("U", "V", "h"), 6 * (2 * 20 + 99 * 400 + 60) * 3),  # config_CMB_h.json net
+}
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PTS_PER_GPU = 1 << 20
 
@@ -88,6 +96,8 @@ def main():
     ap.add_argument("--points", type=int, default=PTS_PER_GPU, help="points per GPU")
     ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 generic, 2 fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="ns8x64", choices=sorted(WORKLOADS),
+                    help="default = the headline BASELINE configs[1]; others are extra evidence, not the contract line")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -97,25 +107,33 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("PINN_BENCH_FORCE_DIST") == "1"     # exercise the RCCL path with one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     from pinn_depthestimation_amd import Engine, NetDesc, ResidualSpec
     from pinn_depthestimation_amd.dnn import init_flat_params
 
-    desc = NetDesc(3, 4, 8, 64, (0, 1, 2), engine=args.engine)
-    spec = ResidualSpec.from_names("Navier_Stokes", ("t", "x", "y"), desc.grad_cols, ("h", "z", "u", "v"))
+    d_in, d_out, hidden, width, gcols, res_name, in_names, out_names, flop_pt = WORKLOADS[args.workload]
+    desc = NetDesc(d_in, d_out, hidden, width, gcols, engine=args.engine)
+    spec = ResidualSpec.from_names(res_name, in_names, desc.grad_cols, out_names)
     eng = Engine(desc, dev)
     P = desc.n_params
     g = torch.Generator().manual_seed(1234)              # same weights on every rank
     params = init_flat_params(desc.layers, "xavier", g).to(dev)
     gx = torch.Generator().manual_seed(1234 + 7919 * rank)  # each rank its own shard of points
     N = args.points
-    X = (torch.rand(N, 3, generator=gx) * 2 - 1).to(dev)
+    if res_name == "physics_equation":                    # keep eta_mean + h away from 0
+        from pinn_depthestimation_amd.engine import NetDesc as _N
+        off_b = P - d_out
+        params[off_b + out_names.index("h")] = 0.75
+        params[off_b + out_names.index("eta_mean")] = 0.0
+    X = (torch.rand(N, d_in, generator=gx) * 2 - 1).to(dev)
     n_global = N * world
-    scale = torch.full((3,), 1.0 / n_global, device=dev)
-    buf = torch.zeros(P + 3, device=dev)                  # [grad | term sums]: ONE all-reduce per step
+    nt = spec.n_terms
+    scale = torch.full((nt,), 1.0 / n_global, device=dev)
+    buf = torch.zeros(P + nt, device=dev)                 # [grad | term sums]: ONE all-reduce per step
     grad, sums = buf[:P], buf[P:]
     m, v = torch.zeros(P, device=dev), torch.zeros(P, device=dev)
     lr0, gamma, sched_step = 1e-4, 0.8, 10000            # config_CMB.json:11-16
@@ -127,7 +145,7 @@ def main():
         if timed_idx is not None: ev[timed_idx][0].record()
         eng.residual_loss_grad(spec, scale, params, X, grad, sums=sums)
         if timed_idx is not None: ev[timed_idx][1].record()
-        if world > 1:
+        if dist is not None:
             dist.all_reduce(buf)
         lr = lr0 * gamma ** (i // sched_step)
         eng.adam_step(params, grad, m, v, i + 1, lr)
@@ -160,31 +178,32 @@ def main():
         traffic = None   # HBM bytes per launch from the committed PMC passes of this same command
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "fused_v3_pmc_summary.json")))
-            if args.engine in (0, 2):
+            if args.engine in (0, 2) and args.workload == "ns8x64":
                 traffic = pm["hbm_bytes_per_point"] * N
         except Exception:
             pass
-        achieved = N * FLOP_PER_POINT / (kern_ms * 1e-3) / 1e12
+        achieved = N * flop_pt / (kern_ms * 1e-3) / 1e12
         out = {
             "metric": "collocation-point residuals/sec (fwd+PDE-grad+Adam)",
             "value": n_global * args.steps / dt, "unit": "residual-points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 3->8x64 tanh->4 MLP, Navier_Stokes residual, "
-                                   f"{N} synthetic (t,x,y) points per GPU, full-batch Adam step",
+            "config": {"workload": (f"BASELINE configs[1]: " if args.workload == "ns8x64" else f"[{args.workload}] ") +
+                                   f"{d_in}->{hidden}x{width} tanh->{d_out} MLP, {res_name} residual, "
+                                   f"{N} synthetic ({','.join(in_names)}) points per GPU, full-batch Adam step",
                        "points_per_gpu": N, "global_points": n_global, "params": P,
                        "parallelism": f"dp{world}", "engine": args.engine, "final_loss": loss},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/r01/fused_v3_pmc_summary.json",
                          "kernel": "pinn_residual_loss_grad (fwd jet + residual + reverse sweep)",
-                         "kernel_ms": kern_ms, "flop_per_point": FLOP_PER_POINT},
+                         "kernel_ms": kern_ms, "flop_per_point": flop_pt},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "ns8x64":
             out["cpu_baseline"] = cpu_baseline(usable_cpus())
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 
