@@ -132,7 +132,7 @@ int32_t pinn_query_workspace(const pinn_desc* desc, int64_t N, int64_t* bytes) {
 static int32_t forward_impl(const pinn_desc* desc, const float* params, const float* X, int64_t N, float* Y,
                             float* dY, void* ws, int64_t ws_bytes, void* stream, bool jet) {
   Net n; int rc = make_net(desc, &n); if (rc) return rc;
-  if (!params || !X || N < 0 || !Y || (jet && !dY)) { set_error("NULL pointer argument"); return PINN_ERR_INVALID; }
+  if (!params || (!X && N > 0) || N < 0 || (!Y && N > 0) || (jet && !dY && N > 0)) { set_error("NULL pointer argument"); return PINN_ERR_INVALID; }
   if (N == 0) return PINN_OK;
   if (!jet) { n.k = 0; n.K1 = 1; dY = nullptr; }
   if (jet && n.k == 0) { set_error("forward_jet needs k >= 1"); return PINN_ERR_INVALID; }
@@ -154,7 +154,7 @@ int32_t pinn_forward_jet(const pinn_desc* desc, const float* params, const float
 int32_t pinn_jet_backward(const pinn_desc* desc, const float* params, const float* X, int64_t N, const float* gY,
                           const float* gdY, float* grad_flat, void* ws, int64_t ws_bytes, void* stream) {
   Net n; int rc = make_net(desc, &n); if (rc) return rc;
-  if (!params || !X || N < 0 || !grad_flat || (!gY && !gdY)) { set_error("NULL pointer argument"); return PINN_ERR_INVALID; }
+  if (!params || (!X && N > 0) || N < 0 || !grad_flat || (!gY && !gdY && N > 0)) { set_error("NULL pointer argument"); return PINN_ERR_INVALID; }
   if (N == 0) return PINN_OK;
   if (!gdY) { n.k = 0; n.K1 = 1; }
   // generic consumer of the jet: the layer-wise engine handles every shape
@@ -166,7 +166,7 @@ static int32_t residual_impl(const pinn_desc* desc, const pinn_residual_spec* sp
                              void* ws, int64_t ws_bytes, void* stream, bool want_grad) {
   Net n; int rc = make_net(desc, &n); if (rc) return rc;
   rc = check_spec(n, spec); if (rc) return rc;
-  if (!params || !X || N < 0 || !term_sums || (want_grad && (!grad_flat || !term_scale))) {
+  if (!params || (!X && N > 0) || N < 0 || !term_sums || (want_grad && (!grad_flat || !term_scale))) {
     set_error("NULL pointer argument"); return PINN_ERR_INVALID;
   }
   LossReq rq; memset(&rq, 0, sizeof(rq));
@@ -193,7 +193,7 @@ int32_t pinn_mse_loss_grad(const pinn_desc* desc, const float* params, const flo
                            int32_t n_cols, const int32_t* out_col, const float* col_scale, float* col_sums,
                            float* grad_flat, void* ws, int64_t ws_bytes, void* stream) {
   Net n; int rc = make_net(desc, &n); if (rc) return rc;
-  if (!params || !X || !T || N < 0 || !out_col || !col_sums || (grad_flat && !col_scale)) {
+  if (!params || ((!X || !T) && N > 0) || N < 0 || !out_col || !col_sums || (grad_flat && !col_scale)) {
     set_error("NULL pointer argument"); return PINN_ERR_INVALID;
   }
   if (n_cols < 1 || n_cols > PINN_MAX_ROLES) { set_error("n_cols=%d outside 1..%d", n_cols, PINN_MAX_ROLES); return PINN_ERR_INVALID; }
