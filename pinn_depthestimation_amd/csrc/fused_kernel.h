@@ -36,9 +36,8 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #endif
 constexpr int FUSED_WAVES = PINN_FUSED_WAVES;
 constexpr int FUSED_THREADS = FUSED_WAVES * 64;
-constexpr int TB_STRIDE = 20;                 // floats per row of a transpose block (80 B: conflict-free b128 writes)
-constexpr int TB_FLOATS = 16 * TB_STRIDE;     // one 16x16 block
-constexpr int TB_PER_WAVE = 4;           // two pads for the Zbar transposes, two for the A transposes
+constexpr int TB_FLOATS = 256;                // one 16x16 fp32 block, XOR-swizzled (see transpose_write)
+constexpr int TB_PER_WAVE = 8;                // 4 pads for the Zbar tiles + 4 for the A tiles of one quantity
 constexpr int MAX_SUMS = 8;
 
 struct FusedParams {
@@ -196,14 +195,21 @@ __device__ __forceinline__ float row_sum16(float v) {
 }
 
 // acc-layout 16x16 block (features x points) -> operand layout of the weight-gradient GEMM:
-// lane (m = lane&15 feature, kq = lane>>4), element s  <-  value(feature m, point 4s + kq)
-__device__ __forceinline__ f4 transpose_block(float* __restrict__ tb, f4 v, int p, int q) {
-  // LDS instructions of one wave execute in program order and the compiler keeps these may-alias
-  // accesses ordered, so the cross-lane exchange needs no barrier.
-  *reinterpret_cast<f4*>(tb + p * TB_STRIDE + 4 * q) = v;     // row p holds the 16 features of point p
+// lane (m = lane&15 feature, kq = lane>>4), element s  <-  value(feature m, point 4s + kq).
+// Pad layout: row = point (64 B), 16-byte chunk c of a row stored at chunk c ^ (point & 3):
+// the b32 column reads are conflict-free, the b128 row writes 2-way.  All writes of a batch are
+// issued before any read so the LDS round trip is paid once per batch, not once per block
+// (one wave's LDS instructions execute in program order: no barrier needed).
+__device__ __forceinline__ void transpose_write(float* __restrict__ tb, f4 v, int p, int q) {
+  *reinterpret_cast<f4*>(tb + p * 16 + 4 * (q ^ (p & 3))) = v;
+}
+__device__ __forceinline__ f4 transpose_read(const float* __restrict__ tb, int p, int q) {
   f4 o;
 #pragma unroll
-  for (int s = 0; s < 4; ++s) o[s] = tb[(4 * s + q) * TB_STRIDE + p];
+  for (int s = 0; s < 4; ++s) {
+    const int pt = 4 * s + q;                               // point index of this k-step for lane group q
+    o[s] = tb[pt * 16 + 4 * ((p >> 2) ^ (pt & 3)) + (p & 3)];   // feature p of that point
+  }
   return o;
 }
 
@@ -270,17 +276,30 @@ __device__ __forceinline__ void weight_grad(const Sink& sink, int layer, int wof
   for (int MT = 0; MT < MT_N; ++MT)
 #pragma unroll
     for (int NT = 0; NT < NT_N; ++NT) dw[MT][NT] = f4{0.f, 0.f, 0.f, 0.f};
+  // Transposes run one quantity AHEAD of the MFMAs that consume them: the LDS round trip of
+  // quantity c+1 (same pads: quantity c's reads have already landed in registers) overlaps the
+  // MT_N*NT_N*4 MFMAs of quantity c.
+  f4 zt[2][MT_N], at[2][NT_N];
+  auto stage = [&](int c, f4 (&z)[MT_N], f4 (&a)[NT_N]) {
+#pragma unroll
+    for (int MT = 0; MT < MT_N; ++MT) transpose_write(tb + MT * TB_FLOATS, Z[c][MT], p, q);
+#pragma unroll
+    for (int NT = 0; NT < NT_N; ++NT) transpose_write(tb + (4 + NT) * TB_FLOATS, A[c][NT], p, q);
+#pragma unroll
+    for (int MT = 0; MT < MT_N; ++MT) z[MT] = transpose_read(tb + MT * TB_FLOATS, p, q);
+#pragma unroll
+    for (int NT = 0; NT < NT_N; ++NT) a[NT] = transpose_read(tb + (4 + NT) * TB_FLOATS, p, q);
+  };
+  stage(0, zt[0], at[0]);
 #pragma unroll
   for (int c = 0; c < K1; ++c) {
-    f4 zt[MT_N], at[NT_N];
-#pragma unroll
-    for (int MT = 0; MT < MT_N; ++MT) zt[MT] = transpose_block(tb + (MT & 1) * TB_FLOATS, Z[c][MT], p, q);
-#pragma unroll
-    for (int NT = 0; NT < NT_N; ++NT) at[NT] = transpose_block(tb + (2 + (NT & 1)) * TB_FLOATS, A[c][NT], p, q);
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 1 < K1) stage(c + 1, zt[(c + 1) & 1], at[(c + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
     if (c == 0) {   // bias: zt[MT][s] = zbar(feature p, point 4s + q): sum the 4 regs, then the 4 lane groups
 #pragma unroll
       for (int MT = 0; MT < MT_N; ++MT) {
-        float t = (zt[MT][0] + zt[MT][1]) + (zt[MT][2] + zt[MT][3]);
+        float t = (zt[0][MT][0] + zt[0][MT][1]) + (zt[0][MT][2] + zt[0][MT][3]);
         t += __shfl_xor(t, 16, 64);
         t += __shfl_xor(t, 32, 64);
         bs[MT] = t;
@@ -291,7 +310,7 @@ __device__ __forceinline__ void weight_grad(const Sink& sink, int layer, int wof
 #pragma unroll
       for (int MT = 0; MT < MT_N; ++MT)
 #pragma unroll
-        for (int NT = 0; NT < NT_N; ++NT) dw[MT][NT] = mfma4(zt[MT][s], at[NT][s], dw[MT][NT]);
+        for (int NT = 0; NT < NT_N; ++NT) dw[MT][NT] = mfma4(zt[c & 1][MT][s], at[c & 1][NT][s], dw[MT][NT]);
   }
   sink.lock(layer, lane);
 #pragma unroll
