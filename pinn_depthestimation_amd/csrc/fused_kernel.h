@@ -132,16 +132,17 @@ __device__ __forceinline__ void init_bias(const float* __restrict__ b, f4 (&acc)
   }
 }
 
-// tanh only: every reference config uses init_type 'xavier' (dnn.py:18-19); LeakyReLU nets run
-// on the generic engine.
-template <int NT, int K1>
+// activation and its first derivative (dnn.py:18-21): tanh ('xavier') or LeakyReLU(0.01) ('kaiming')
+template <int ACT, int NT, int K1>
 __device__ __forceinline__ void activate(f4 (&acc)[K1][NT]) {
 #pragma unroll
   for (int MT = 0; MT < NT; ++MT)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float a = tanh_f32(acc[0][MT][r]);
-      const float s = fmaf(-a, a, 1.f);
+      const float z = acc[0][MT][r];
+      float a, s;
+      if constexpr (ACT == PINN_ACT_TANH) { a = tanh_f32(z); s = fmaf(-a, a, 1.f); }
+      else { a = z > 0.f ? z : 0.01f * z; s = z > 0.f ? 1.f : 0.01f; }
       acc[0][MT][r] = a;
 #pragma unroll
       for (int c = 1; c < K1; ++c) acc[c][MT][r] *= s;
@@ -149,21 +150,27 @@ __device__ __forceinline__ void activate(f4 (&acc)[K1][NT]) {
 }
 
 // adjoint of activate(): G holds (abar', abardot'_j) on entry, (zbar, zbardot_j) on exit
-template <int NT, int K1>
+template <int ACT, int NT, int K1>
 __device__ __forceinline__ void activate_adjoint(f4 (&G)[K1][NT], const f4 (&A)[K1][NT]) {
 #pragma unroll
   for (int MT = 0; MT < NT; ++MT)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float a = A[0][MT][r];
-      const float s = fmaf(-a, a, 1.f);
-      float cross = 0.f;
+      if constexpr (ACT == PINN_ACT_TANH) {
+        const float s = fmaf(-a, a, 1.f);
+        float cross = 0.f;
 #pragma unroll
-      for (int c = 1; c < K1; ++c) {
-        cross = fmaf(G[c][MT][r], A[c][MT][r], cross);
-        G[c][MT][r] *= s;
+        for (int c = 1; c < K1; ++c) {
+          cross = fmaf(G[c][MT][r], A[c][MT][r], cross);
+          G[c][MT][r] *= s;
+        }
+        G[0][MT][r] = fmaf(-2.f * a, cross, s * G[0][MT][r]);   // tanh'' = -2 a (1 - a^2)
+      } else {
+        const float s = a > 0.f ? 1.f : 0.01f;                   // piecewise linear: no second-derivative term
+#pragma unroll
+        for (int c = 0; c < K1; ++c) G[c][MT][r] *= s;
       }
-      G[0][MT][r] = fmaf(-2.f * a, cross, s * G[0][MT][r]);   // tanh'' = -2 a (1 - a^2)
     }
 }
 
@@ -415,7 +422,7 @@ __device__ __forceinline__ void residual_tile(const FusedParams& P, const f4 (&o
 #define PINN_STAMP(i) do { } while (0)
 #endif
 
-template <int WP, int K1, bool GRAD, bool LDSACC>
+template <int WP, int K1, bool GRAD, bool LDSACC, int ACT>
 __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const FusedParams P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NTH = WP / 16;
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
     init_bias<NTH, K1>(P.Bp + b_off_p<WP>(0), a, q);
     gemm_chain<1, NTH, K1>(w0, b0, a);
     PINN_STAMP(0);
-    activate<NTH, K1>(a);
+    activate<ACT, NTH, K1>(a);
     if (GRAD) spill<NTH, K1>(scr, a, lane);
     PINN_STAMP(1);
     for (int l = 1; l < L; ++l) {
@@ -501,7 +508,7 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
       init_bias<NTH, K1>(P.Bp + b_off_p<WP>(l), nx, q);
       gemm_chain<NTH, NTH, K1>(wh, a, nx);
       PINN_STAMP(0);
-      activate<NTH, K1>(nx);
+      activate<ACT, NTH, K1>(nx);
       if (GRAD) spill<NTH, K1>(scr + l * SLOT, nx, lane);
       PINN_STAMP(1);
       copy_tiles<NTH, K1>(a, nx);
@@ -579,7 +586,7 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
       for (int l = L - 1; l >= 1; --l) {
         // hidden layer l: output a_{l+1} (= ao), input a_l (= ai), W_l^T (= wt)
         PINN_STAMP(3);
-        activate_adjoint<NTH, K1>(g, ao);
+        activate_adjoint<ACT, NTH, K1>(g, ao);
         PINN_STAMP(4);
         weight_grad<NTH, NTH, K1>(sink, l, w_off_p<WP>(l), P.PW + b_off_p<WP>(l), g, ai, tb, lane);
         PINN_STAMP(5);
@@ -597,7 +604,7 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
         copy_w<NTH, NTH>(wt, wtn);
       }
       {  // layer 0: output a_1 (= ao), input = (x, unit tangents)
-        activate_adjoint<NTH, K1>(g, ao);
+        activate_adjoint<ACT, NTH, K1>(g, ao);
         f4 b1[K1][1];
         input_jet(b1);   // recomputed rather than kept live across the whole tile
         weight_grad<NTH, 1, K1>(sink, 0, 0, P.PW + b_off_p<WP>(0), g, b1, tb, lane);

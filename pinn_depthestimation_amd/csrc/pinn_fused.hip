@@ -216,7 +216,7 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
 
 bool fused_supports(const Net& n) {
   if (n.L + 1 > MAX_LOCKS) return false;
-  return n.act == PINN_ACT_TANH && n.W <= 64 && n.d_in <= 16 && n.d_out <= 16 && n.L >= 1 && n.K1 >= 1 && n.K1 <= 4;
+  return n.W <= 64 && n.d_in <= 16 && n.d_out <= 16 && n.L >= 1 && n.K1 >= 1 && n.K1 <= 4;
 }
 
 int64_t fused_workspace_bytes(const Net& n, int64_t N) {

@@ -4,15 +4,21 @@
 
 namespace pinn {
 
-template <int K1, bool GRAD, bool LDSACC>
-static int launch_one(const FusedParams& P, int grid, size_t lds, hipStream_t s) {
-  auto kern = k_fused<64, K1, GRAD, LDSACC>;
+template <int K1, bool GRAD, bool LDSACC, int ACT>
+static int launch_one_act(const FusedParams& P, int grid, size_t lds, hipStream_t s) {
+  auto kern = k_fused<64, K1, GRAD, LDSACC, ACT>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e)); return PINN_ERR_LAUNCH; }
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(FUSED_THREADS), lds, s, P);
   return check_launch("fused kernel (WP=64)");
+}
+
+template <int K1, bool GRAD, bool LDSACC>
+static int launch_one(const FusedParams& P, int grid, size_t lds, hipStream_t s) {
+  return P.act == PINN_ACT_TANH ? launch_one_act<K1, GRAD, LDSACC, PINN_ACT_TANH>(P, grid, lds, s)
+                                : launch_one_act<K1, GRAD, LDSACC, PINN_ACT_LEAKY_RELU>(P, grid, lds, s);
 }
 
 template <>

@@ -51,6 +51,12 @@ class HipEvaluator:
         else:
             res_sums.zero_()
 
+    def adam_step(self, theta, grad, m, v, step, lr):
+        self.eng.adam_step(theta, grad, m, v, step, lr)
+
+    def predict(self, theta, X):
+        return self.eng.forward(theta, X)
+
 
 class PINN:
     """The physics-guided network harness (reference `class pinn`, train.py:46)."""
@@ -59,7 +65,7 @@ class PINN:
                  device="cuda", log_dir: Optional[str] = None, log_every: int = 1, checkpoint_every: int = 1000,
                  reducer: Optional[Reducer] = None, evaluator: Optional[Callable] = None,
                  dnn: Optional[DNN] = None, engine: int = 0, mat_dump_iter: Optional[int] = None,
-                 mat_dump_path: str = "data_at50k.mat"):
+                 mat_dump_path: str = "data_at50k.mat", residual_batch: Optional[int] = None, seed: int = 1234):
         cfg = config if isinstance(config, PinnConfig) else load_config(config)
         self.config, self.device = cfg, torch.device(device)
         self.reducer = reducer or Reducer()
@@ -103,6 +109,16 @@ class PINN:
         self.evaluator = evaluator or HipEvaluator(cfg.layers, cfg.init_type, cfg.grad_cols, self.spec,
                                                    self.fid_cols, dev, engine)
 
+        # optional resampled collocation mini-batch (the reference is full-batch only):
+        # each closure draws `residual_batch` of this rank's points with a device-side generator
+        self.residual_batch = residual_batch
+        self._gen = None
+        if residual_batch is not None:
+            if residual == "continuity_only":
+                raise PinnError("residual_batch is not supported with continuity_only's data-dependent mean")
+            self._gen = torch.Generator(device=dev).manual_seed(seed + self.reducer.rank)
+            self._res_unit = torch.full((nt,), 1.0 / (residual_batch * self.reducer.world), dtype=torch.float32, device=dev)
+            self._res_scale = (self.weight_residual * self._res_unit).contiguous()
         self.mat_dump_iter, self.mat_dump_path = mat_dump_iter, mat_dump_path
         self.iter = 0                                                      # train.py:73
         self.adam_maxit = cfg.adam["max_it"]
@@ -137,7 +153,11 @@ class PINN:
         if self.mat_dump_iter is not None and self.iter == self.mat_dump_iter:
             self.dump_predictions(self.mat_dump_path)                      # train_newmethod.py:141-153
         self.buf.zero_()
-        self.evaluator(self.theta, self.Xf, self.Tf, self._fid_scale, self.Xr, self._res_scale, self.grad,
+        Xr = self.Xr
+        if self.residual_batch is not None:
+            idx = torch.randint(0, self.Xr.shape[0], (self.residual_batch,), device=self.device, generator=self._gen)
+            Xr = self.Xr.index_select(0, idx)
+        self.evaluator(self.theta, self.Xf, self.Tf, self._fid_scale, Xr, self._res_scale, self.grad,
                        self._fid_sums, self._res_sums)
         self.reducer.allreduce_sum_(self.buf)
         fidelity_loss = (self._fid_sums * self._fid_unit).sum()
@@ -189,12 +209,8 @@ class PINN:
         """zero_grad / loss_func / backward / Adam.step / StepLR.step (train.py:189-193)."""
         loss = self.loss_func()
         self._adam_step += 1
-        eng = getattr(self.evaluator, "eng", None)
-        lr = self.current_lr()
-        if eng is not None:
-            eng.adam_step(self.theta, self.grad, self._adam_m, self._adam_v, self._adam_step, lr)
-        else:   # injected evaluator (CPU tests): same arithmetic in torch
-            _torch_adam(self.theta, self.grad, self._adam_m, self._adam_v, self._adam_step, lr)
+        self.evaluator.adam_step(self.theta, self.grad, self._adam_m, self._adam_v, self._adam_step,
+                                 self.current_lr())
         self._sched_steps += 1
         return loss
 
@@ -216,19 +232,7 @@ class PINN:
     def predict(self, inputs) -> torch.Tensor:
         """Forward on a grid (test.py:76): (N, d_in) -> (N, d_out)."""
         X = _as_f32(inputs, self.device)
-        eng = getattr(self.evaluator, "eng", None)
-        if eng is None:
-            raise PinnError("predict needs the HIP evaluator")
-        return eng.forward(self.dnn.flat_params(), X)
-
-
-def _torch_adam(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
-    """torch.optim.Adam's single-tensor update, used only with an injected evaluator."""
-    m.lerp_(g, 1 - b1)
-    v.mul_(b2).addcmul_(g, g, value=1 - b2)
-    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
-    denom = (v.sqrt() / (bc2 ** 0.5)).add_(eps)
-    p.addcdiv_(m, denom, value=-lr / bc1)
+        return self.evaluator.predict(self.dnn.flat_params(), X)
 
 
 pinn = PINN   # the reference's class name (train.py:46)

@@ -134,16 +134,28 @@ def test_jet_backward_matches_autograd(engine):
     assert rel_l2(grad.cpu(), go) < 2e-5
 
 
-def test_leaky_relu_generic():
-    d = NetDesc(2, 3, 3, 16, (0, 1), ACT_LEAKY_RELU, ENGINE_GENERIC)
+@pytest.mark.parametrize("engine", ENGINES)
+def test_leaky_relu_kaiming_network(engine):
+    """init_type 'kaiming' -> LeakyReLU(0.01) (dnn.py:20-21): jet, loss and gradient on both engines."""
+    d = NetDesc(2, 3, 3, 16, (0, 1), ACT_LEAKY_RELU, engine)
     g = torch.Generator().manual_seed(5)
     params = O.init_params(d.layers, "kaiming", g)
-    X = torch.rand(100, 2, generator=g) * 2 - 1
+    X = torch.rand(333, 2, generator=g) * 2 - 1
     eng = Engine(d)
-    Y, dY = eng.forward_jet(O.flatten(params).cuda(), X.cuda())
+    flat = O.flatten(params).cuda()
+    Y, dY = eng.forward_jet(flat, X.cuda())
     Yo, dYo = O.jet([p.double() for p in params], X.double(), (0, 1), "kaiming")
     assert (Y.cpu().double() - Yo).abs().max() < 2e-6
     assert (dY.cpu().double() - dYo).abs().max() < 5e-6
+    p64 = [p.double().requires_grad_(True) for p in params]
+    lo = O.residual_loss(p64, X.double(), "continuity_ftemp", [0, 1], [2, 0, 1], (0, 1), "kaiming")
+    go = O.flat_grad(lo, p64)
+    spec = ResidualSpec.from_names("continuity_ftemp", ("x", "y"), (0, 1), ("U", "V", "h"))
+    grad = torch.zeros(d.n_params, device="cuda")
+    scale = torch.full((1,), 1.0 / 333, device="cuda")
+    sums = eng.residual_loss_grad(spec, scale, flat, X.cuda(), grad)
+    assert abs(float(sums[0]) / 333 - float(lo)) / float(lo) < 5e-6
+    assert rel_l2(grad.cpu(), go) < 2e-5
 
 
 def test_adam_step_matches_torch():

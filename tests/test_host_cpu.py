@@ -256,6 +256,15 @@ def _oracle_evaluator(cfg_layers, spec_name, in_roles, out_roles, grad_cols, fid
         else:
             res_sums.zero_()
         grad.add_(O.flat_grad(obj, p))
+
+    def adam_step(theta, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
+        """torch.optim.Adam's single-tensor update (what pinn_adam_step reproduces bit-for-bit on the GPU)"""
+        m.lerp_(g, 1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (v.sqrt() / ((1 - b2 ** step) ** 0.5)).add_(eps)
+        theta.addcdiv_(m, denom, value=-lr / (1 - b1 ** step))
+
+    ev.adam_step = adam_step
     return ev
 
 

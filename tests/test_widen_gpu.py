@@ -92,3 +92,20 @@ def test_mat_dump_and_checkpoint_formats(tmp_path):
     assert torch.equal(whole.state_dict()["layers.layer_3.weight"].cpu(), sd2["layers.layer_3.weight"].cpu())
     rows = open(tmp_path / "log.txt").read().splitlines()
     assert rows[0].startswith("Epoch, Fidelity Loss") and len(rows) == 4 and rows[3].startswith("3, ")
+
+
+def test_minibatch_resampled_collocation_is_seeded_and_descends():
+    """resampled collocation mini-batches (the reference is full-batch only)."""
+    import dnn
+    from pinn_depthestimation_amd.trainer import pinn
+    z0, z7 = load("g1_g3_ns_8x64.npz"), load("g7_adam_ns_8x64.npz")
+    runs = []
+    for _ in range(2):
+        model = dnn.DNN([3] + [64] * 8 + [4], 0.0, "xavier")
+        model.load_state_dict(state_dict(z0))
+        tr = pinn(None, None, z7["X"], ns_config(60), dnn=model, log_every=1, checkpoint_every=0,
+                  residual_batch=2048, seed=77)
+        tr.train()
+        runs.append(np.array([h[3] for h in tr.history]))
+    assert np.array_equal(runs[0], runs[1])                      # same seed -> same batches -> same trajectory
+    assert runs[0][-5:].mean() < 0.05 * runs[0][:5].mean()       # and it trains
