@@ -107,5 +107,7 @@ def test_minibatch_resampled_collocation_is_seeded_and_descends():
                   residual_batch=2048, seed=77)
         tr.train()
         runs.append(np.array([h[3] for h in tr.history]))
-    assert np.array_equal(runs[0], runs[1])                      # same seed -> same batches -> same trajectory
+    # same seed -> same batches; the per-workgroup LDS accumulation order is not fixed, so two runs
+    # agree to rounding (observed ~1e-8), not bit for bit
+    assert np.allclose(runs[0], runs[1], rtol=1e-5, atol=0)
     assert runs[0][-5:].mean() < 0.05 * runs[0][:5].mean()       # and it trains
