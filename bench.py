@@ -29,6 +29,7 @@ WORKLOADS = {
     "ns8x64": (3, 4, 8, 64, (0, 1, 2), "Navier_Stokes", ("t", "x", "y"), ("h", "z", "u", "v"), 695_424),          # BASELINE configs[1]
     "pe8x64": (2, 6, 8, 64, (0, 1), "physics_equation", ("x", "y"), ("h", "U", "V", "eta_mean", "Hrms", "k"), 523_776),  # configs[2], 8x64
     "pe10x10": (2, 6, 10, 10, (0, 1), "physics_equation", ("x", "y"), ("h", "U", "V", "eta_mean", "Hrms", "k"), 17_400),  # configs[2] as written
+    "ns12x256": (3, 4, 12, 256, (0, 1, 2), "Navier_Stokes", ("t", "x", "y"), ("h", "z", "u", "v"), 17_330_688),  # configs[3] shape, fp32
     "co100x20": (2, 3, 100, 20, (0, 1), "continuity_ftemp", ("x", "y"), ("U", "V", "h"), 6 * (2 * 20 + 99 * 400 + 60) * 3),  # config_CMB_h.json net
 }
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak

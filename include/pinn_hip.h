@@ -54,7 +54,8 @@ extern "C" {
 /* engine selector (0 lets the library pick the fastest kernel that supports the shape) */
 #define PINN_ENGINE_AUTO 0
 #define PINN_ENGINE_GENERIC 1  /* layer-by-layer VALU kernels, any shape */
-#define PINN_ENGINE_FUSED 2    /* MFMA chain kernel, hidden width <= 64 */
+#define PINN_ENGINE_FUSED 2    /* MFMA chain kernel, one persistent launch, hidden width <= 64 */
+#define PINN_ENGINE_WIDE 3     /* MFMA chain, one launch per layer, 64 < hidden width <= 256 */
 
 /* error codes */
 #define PINN_OK 0

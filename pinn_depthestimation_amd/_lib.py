@@ -14,7 +14,7 @@ PINN_MAX_DIRS = 3
 PINN_MAX_ROLES = 8
 
 ACT_TANH, ACT_LEAKY_RELU = 0, 1
-ENGINE_AUTO, ENGINE_GENERIC, ENGINE_FUSED = 0, 1, 2
+ENGINE_AUTO, ENGINE_GENERIC, ENGINE_FUSED, ENGINE_WIDE = 0, 1, 2, 3
 
 RES_NAVIER_STOKES, RES_PHYSICS_EQUATION, RES_CONTINUITY_FTEMP, RES_CONTINUITY_ONLY = 1, 2, 3, 4
 RES_TERMS = {RES_NAVIER_STOKES: 3, RES_PHYSICS_EQUATION: 3, RES_CONTINUITY_FTEMP: 1, RES_CONTINUITY_ONLY: 3}

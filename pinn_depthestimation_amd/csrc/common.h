@@ -57,6 +57,14 @@ int fused_forward(const Net& n, const float* params, const float* X, int64_t N, 
 int fused_loss(const Net& n, const LossReq& rq, const float* params, const float* X, int64_t N,
                void* ws, int64_t ws_bytes, hipStream_t s);
 
+// wide MFMA engine, 64 < W <= 256 (pinn_wide.hip)
+bool wide_supports(const Net& n);
+int64_t wide_workspace_bytes(const Net& n, int64_t N);
+int wide_forward(const Net& n, const float* params, const float* X, int64_t N, float* Y, float* dY,
+                 void* ws, int64_t ws_bytes, hipStream_t s);
+int wide_loss(const Net& n, const LossReq& rq, const float* params, const float* X, int64_t N,
+              void* ws, int64_t ws_bytes, hipStream_t s);
+
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

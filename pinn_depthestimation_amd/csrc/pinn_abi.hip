@@ -38,15 +38,22 @@ int make_net(const pinn_desc* d, Net* n) {
   return PINN_OK;
 }
 
-static bool use_fused(const pinn_desc* d, const Net& n, int* rc) {
+// 1 = generic, 2 = fused, 3 = wide
+static int pick_engine(const pinn_desc* d, const Net& n, int* rc) {
   *rc = PINN_OK;
-  if (d->engine == PINN_ENGINE_GENERIC) return false;
-  const bool ok = fused_supports(n);
-  if (d->engine == PINN_ENGINE_FUSED && !ok) {
-    set_error("fused engine does not support this shape (width %d, d_in %d, d_out %d)", n.W, n.d_in, n.d_out);
-    *rc = PINN_ERR_UNSUPPORTED;
+  if (d->engine == PINN_ENGINE_GENERIC) return PINN_ENGINE_GENERIC;
+  if (d->engine == PINN_ENGINE_FUSED || d->engine == PINN_ENGINE_WIDE) {
+    const bool ok = d->engine == PINN_ENGINE_FUSED ? fused_supports(n) : wide_supports(n);
+    if (!ok) {
+      set_error("%s engine does not support this shape (width %d, d_in %d, d_out %d, k %d, act %d)",
+                d->engine == PINN_ENGINE_FUSED ? "fused" : "wide", n.W, n.d_in, n.d_out, n.k, n.act);
+      *rc = PINN_ERR_UNSUPPORTED;
+    }
+    return d->engine;
   }
-  return ok;
+  if (fused_supports(n)) return PINN_ENGINE_FUSED;
+  if (wide_supports(n)) return PINN_ENGINE_WIDE;
+  return PINN_ENGINE_GENERIC;
 }
 
 static int residual_terms(int id) {
@@ -121,9 +128,10 @@ int32_t pinn_param_count(const pinn_desc* desc, int64_t* count) {
 int32_t pinn_query_workspace(const pinn_desc* desc, int64_t N, int64_t* bytes) {
   Net n; int rc = make_net(desc, &n); if (rc) return rc;
   if (!bytes || N < 0) { set_error("bad arguments"); return PINN_ERR_INVALID; }
-  bool fused = use_fused(desc, n, &rc); if (rc) return rc;
+  const int e = pick_engine(desc, n, &rc); if (rc) return rc;
   // one workspace must serve every call on this network, including plain (k = 0) forwards
-  int64_t b = fused ? fused_workspace_bytes(n, N) : generic_workspace_bytes(n, N);
+  int64_t b = e == PINN_ENGINE_FUSED ? fused_workspace_bytes(n, N)
+            : e == PINN_ENGINE_WIDE ? wide_workspace_bytes(n, N) : generic_workspace_bytes(n, N);
   if (b < 0) { set_error("network not supported"); return PINN_ERR_UNSUPPORTED; }
   *bytes = b;
   return PINN_OK;
@@ -136,9 +144,11 @@ static int32_t forward_impl(const pinn_desc* desc, const float* params, const fl
   if (N == 0) return PINN_OK;
   if (!jet) { n.k = 0; n.K1 = 1; dY = nullptr; }
   if (jet && n.k == 0) { set_error("forward_jet needs k >= 1"); return PINN_ERR_INVALID; }
-  bool fused = use_fused(desc, n, &rc); if (rc) return rc;
-  return fused ? fused_forward(n, params, X, N, Y, dY, ws, ws_bytes, (hipStream_t)stream)
-               : generic_forward(n, params, X, N, Y, dY, ws, ws_bytes, (hipStream_t)stream);
+  int e = pick_engine(desc, n, &rc); if (rc) return rc;
+  if (e == PINN_ENGINE_WIDE && desc->engine == PINN_ENGINE_AUTO && !wide_supports(n)) e = PINN_ENGINE_GENERIC;
+  return e == PINN_ENGINE_FUSED ? fused_forward(n, params, X, N, Y, dY, ws, ws_bytes, (hipStream_t)stream)
+       : e == PINN_ENGINE_WIDE ? wide_forward(n, params, X, N, Y, dY, ws, ws_bytes, (hipStream_t)stream)
+                               : generic_forward(n, params, X, N, Y, dY, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int32_t pinn_forward(const pinn_desc* desc, const float* params, const float* X, int64_t N, float* Y, void* ws,
@@ -173,9 +183,10 @@ static int32_t residual_impl(const pinn_desc* desc, const pinn_residual_spec* sp
   rq.kind = 0; rq.spec = *spec; rq.scale = term_scale; rq.sums = term_sums;
   rq.grad = want_grad ? grad_flat : nullptr; rq.n_terms = residual_terms(spec->residual_id);
   if (N == 0) { (void)hipMemsetAsync(term_sums, 0, rq.n_terms * sizeof(float), (hipStream_t)stream); return PINN_OK; }
-  bool fused = use_fused(desc, n, &rc); if (rc) return rc;
-  return fused ? fused_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream)
-               : generic_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream);
+  const int e = pick_engine(desc, n, &rc); if (rc) return rc;
+  return e == PINN_ENGINE_FUSED ? fused_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream)
+       : e == PINN_ENGINE_WIDE ? wide_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream)
+                               : generic_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int32_t pinn_residual_loss(const pinn_desc* desc, const pinn_residual_spec* spec, const float* params,
@@ -206,9 +217,10 @@ int32_t pinn_mse_loss_grad(const pinn_desc* desc, const float* params, const flo
   }
   if (N == 0) { (void)hipMemsetAsync(col_sums, 0, n_cols * sizeof(float), (hipStream_t)stream); return PINN_OK; }
   n.k = 0; n.K1 = 1;  // the fidelity term needs no input derivatives
-  bool fused = use_fused(desc, n, &rc); if (rc) return rc;
-  return fused ? fused_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream)
-               : generic_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream);
+  const int e = pick_engine(desc, n, &rc); if (rc) return rc;
+  return e == PINN_ENGINE_FUSED ? fused_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream)
+       : e == PINN_ENGINE_WIDE ? wide_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream)
+                               : generic_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int32_t pinn_adam_step(float* params, const float* grad, float* m, float* v, int64_t P, int64_t step, double lr,

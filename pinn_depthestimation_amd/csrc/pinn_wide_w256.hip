@@ -1,0 +1,78 @@
+// pinn_wide_w256.hip — instantiations of the wide (one launch per layer) MFMA engine, padded width 256
+#include <type_traits>
+#include "wide_kernel.h"
+
+namespace pinn {
+
+constexpr int NTW_ = 16;
+constexpr size_t PADS_LDS = (size_t)(WIDE_WAVES * WIDE_MAX_PADS * TB_FLOATS + WIDE_WAVES * MAX_SUMS) * 4;
+
+template <class K>
+static int go(K kern, const FusedParams& P, const WideLayer& Lp, dim3 grid, size_t lds, hipStream_t s, const char* what) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e)); return PINN_ERR_LAUNCH; }
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(WIDE_THREADS), lds, s, P, Lp);
+  return check_launch(what);
+}
+
+template <int K1>
+static int fwd_k(int which, bool grad, const FusedParams& P, const WideLayer& Lp, int grid, hipStream_t s) {
+  constexpr int A = PINN_ACT_TANH;
+  switch (which) {
+    case 0: return go(k_wide_fwd<1, NTW_, K1, A, true, false, false>, P, Lp, dim3(grid), 0, s, "wide fwd first");
+    case 1: return go(k_wide_fwd<NTW_, NTW_, K1, A, false, false, false>, P, Lp, dim3(grid), 0, s, "wide fwd hidden");
+    default:
+      return grad ? go(k_wide_fwd<NTW_, 1, K1, A, false, true, true>, P, Lp, dim3(grid), PADS_LDS, s, "wide fwd last")
+                  : go(k_wide_fwd<NTW_, 1, K1, A, false, true, false>, P, Lp, dim3(grid), PADS_LDS, s, "wide fwd last");
+  }
+}
+template <>
+int launch_wide_fwd<NTW_>(int which, int K1, int, bool grad, const FusedParams& P, const WideLayer& Lp, int grid, hipStream_t s) {
+  switch (K1) {
+    case 1: return fwd_k<1>(which, grad, P, Lp, grid, s);
+    case 3: return fwd_k<3>(which, grad, P, Lp, grid, s);
+    case 4: return fwd_k<4>(which, grad, P, Lp, grid, s);
+  }
+  set_error("wide engine: no kernel for K1=%d", K1); return PINN_ERR_UNSUPPORTED;
+}
+
+template <int K1>
+static int bwd_k(int which, const FusedParams& P, const WideLayer& Lp, int grid, hipStream_t s) {
+  constexpr int A = PINN_ACT_TANH;
+  switch (which) {
+    case 0: return go(k_wide_bwd<NTW_, 1, K1, A, true, false>, P, Lp, dim3(grid), 0, s, "wide bwd first");
+    case 1: return go(k_wide_bwd<NTW_, NTW_, K1, A, true, true>, P, Lp, dim3(grid), 0, s, "wide bwd hidden");
+    default: return go(k_wide_bwd<1, NTW_, K1, A, false, true>, P, Lp, dim3(grid), 0, s, "wide bwd last");
+  }
+}
+template <>
+int launch_wide_bwd<NTW_>(int which, int K1, int, const FusedParams& P, const WideLayer& Lp, int grid, hipStream_t s) {
+  switch (K1) {
+    case 1: return bwd_k<1>(which, P, Lp, grid, s);
+    case 3: return bwd_k<3>(which, P, Lp, grid, s);
+    case 4: return bwd_k<4>(which, P, Lp, grid, s);
+  }
+  set_error("wide engine: no kernel for K1=%d", K1); return PINN_ERR_UNSUPPORTED;
+}
+
+template <int K1>
+static int wg_k(int which, const FusedParams& P, const WideLayer& Lp, int gx, hipStream_t s) {
+  switch (which) {
+    case 0: return go(k_wide_wgrad<4, NTW_, 1, K1, true>, P, Lp, dim3(gx, NTW_ / 4), PADS_LDS, s, "wide wgrad first");
+    case 1: return go(k_wide_wgrad<4, NTW_, NTW_, K1, false>, P, Lp, dim3(gx, NTW_ / 4), PADS_LDS, s, "wide wgrad hidden");
+    default: return go(k_wide_wgrad<1, 1, NTW_, K1, false>, P, Lp, dim3(gx, 1), PADS_LDS, s, "wide wgrad last");
+  }
+}
+template <>
+int launch_wide_wgrad<NTW_>(int which, int K1, const FusedParams& P, const WideLayer& Lp, int gx, hipStream_t s) {
+  switch (K1) {
+    case 1: return wg_k<1>(which, P, Lp, gx, s);
+    case 3: return wg_k<3>(which, P, Lp, gx, s);
+    case 4: return wg_k<4>(which, P, Lp, gx, s);
+  }
+  set_error("wide engine: no kernel for K1=%d", K1); return PINN_ERR_UNSUPPORTED;
+}
+
+}  // namespace pinn

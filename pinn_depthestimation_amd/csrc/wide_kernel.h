@@ -1,0 +1,339 @@
+// wide_kernel.h — MFMA engine for hidden widths 64 < W <= 256 (BASELINE configs[3]: 12 x 256).
+//
+// Same algorithm and the same "acc layout" as fused_kernel.h (forward-mode jet chain on
+// v_mfma_f32_16x16x4_f32, accumulators feed the next MFMA as B operand unchanged), but a
+// 256-wide layer does not fit one wave's registers twice over, so the network is walked ONE
+// LAYER PER LAUNCH:
+//   k_wide_fwd   per 16-point tile: out[K1][NTO] = act(W . in + b); the input jet streams through
+//                registers in 64-feature chunks, the NTO*K1 accumulator tiles (256 VGPR for
+//                16 x 4) stay resident; weights come straight from L2 (every wave of the launch
+//                works on the same layer, so the 256 KB matrix is L2-hot).
+//   k_wide_bwd   zbar = activation adjoint (in place), abar_in = W^T zbar (same chain on W^T).
+//   k_wide_wgrad split-K weight gradient: a wave owns a (64 x in) block of dW in registers and
+//                walks a strided subset of the point tiles (transposing each 16x16 block through
+//                its LDS pads exactly as the fused kernel does); one global atomic flush per wave.
+// Activations live in HBM in fragment-native order [tile][quantity][feature tile][lane][4]
+// (16 B per lane, fully coalesced both ways).  The host loops over point CHUNKS so the
+// activation workspace stays bounded (pinn_wide.hip).
+#pragma once
+#include "fused_kernel.h"
+
+namespace pinn {
+
+constexpr int WIDE_WAVES = 4;
+constexpr int WIDE_THREADS = WIDE_WAVES * 64;
+constexpr int WIDE_MAX_PADS = 20;   // 4 zbar tiles + 16 input tiles of one quantity
+
+struct WideLayer {
+  const float* W;        // this layer's padded weights, row-major [16*NTO][16*NTI] (fwd) or W^T (bwd)
+  const float* b;        // padded bias (fwd)
+  const float* in_act;   // fwd: layer input jet; bwd: a_{l+1} (layer output jet); wgrad: layer input jet
+  float* out_act;        // fwd: layer output jet
+  float* g_in;           // bwd: adjoint of the layer output (overwritten with zbar); wgrad: zbar
+  float* g_out;          // bwd: adjoint of the layer input
+  float* dW;             // wgrad: flat torch-layout gradient of this layer's weight (out_d x in_d)
+  float* db;             // wgrad: gradient of this layer's bias
+  int in_d, out_d;       // real (unpadded) dims of the layer
+  int64_t tile0;         // first global tile of this chunk (for X / T indexing)
+  int64_t n_tiles;       // tiles in this chunk
+  int sums_slot;         // row offset in wg_sums for this chunk
+};
+
+template <int K1>
+__device__ __forceinline__ void wide_input_jet(const FusedParams& P, int64_t ptc, int q, f4 (&b)[K1][1]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int f = 4 * q + r;
+    b[0][0][r] = (f < P.d_in) ? P.X[ptc * P.d_in + f] : 0.f;
+#pragma unroll
+    for (int c = 1; c < K1; ++c) b[c][0][r] = (f == P.dir_col[c - 1]) ? 1.f : 0.f;
+  }
+}
+
+// out = act(W . in + b) for one layer.  FIRST: the input is (x, unit tangents) built from X.
+// LAST: no activation; outputs / loss / output adjoint instead of a stored jet.
+template <int NTI, int NTO, int K1, int ACT, bool FIRST, bool LAST, bool GRAD>
+__global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_fwd(const FusedParams P, const WideLayer Lp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = lane & 15, q = lane >> 4;
+  float* tb = smem + wave * (WIDE_MAX_PADS * TB_FLOATS);
+  float* lsum = smem + WIDE_WAVES * WIDE_MAX_PADS * TB_FLOATS;
+  constexpr int CH = NTI < 4 ? NTI : 4;
+  constexpr int LDW = 16 * NTI;
+  float sums[MAX_SUMS];
+#pragma unroll
+  for (int j = 0; j < MAX_SUMS; ++j) sums[j] = 0.f;
+  ScatterMap<K1> sm;
+  if constexpr (LAST) {
+    const int n_roles = P.loss_kind == 2 ? P.n_cols : PINN_MAX_ROLES;
+#pragma unroll
+    for (int r2 = 0; r2 < 4; ++r2) {
+      int ro = -1;
+      for (int r = PINN_MAX_ROLES - 1; r >= 0; --r) ro = (r < n_roles && P.out_col[r] == 4 * q + r2) ? r : ro;
+      sm.role_of[r2] = ro;
+    }
+    sm.cinv[0] = 0;
+#pragma unroll
+    for (int ce = 1; ce < K1; ++ce) {
+      int ci = -1;
+      for (int d = PINN_MAX_DIRS - 1; d >= 0; --d) ci = (P.q_of[d] == ce) ? 1 + d : ci;
+      sm.cinv[ce] = ci;
+    }
+  }
+  const int gw = blockIdx.x * WIDE_WAVES + wave, nw = gridDim.x * WIDE_WAVES;
+  for (int64_t t = gw; t < Lp.n_tiles; t += nw) {
+    const int64_t pt = (Lp.tile0 + t) * 16 + p;
+    const bool valid = pt < P.N;
+    const int64_t ptc = valid ? pt : P.N - 1;
+    f4 acc[K1][NTO];
+    init_bias<NTO, K1>(Lp.b, acc, q);
+    for (int kc = 0; kc < NTI; kc += CH) {
+      f4 B[K1][CH];
+      if constexpr (FIRST) {
+        f4 b0[K1][1];
+        wide_input_jet<K1>(P, ptc, q, b0);
+#pragma unroll
+        for (int c = 0; c < K1; ++c) B[c][0] = b0[c][0];
+      } else {
+#pragma unroll
+        for (int c = 0; c < K1; ++c)
+#pragma unroll
+          for (int j = 0; j < CH; ++j)
+            B[c][j] = *reinterpret_cast<const f4*>(Lp.in_act + ((t * K1 + c) * NTI + kc + j) * 256 + lane * 4);
+      }
+#pragma unroll
+      for (int MT = 0; MT < NTO; ++MT) {
+        f4 a[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+          a[j] = *reinterpret_cast<const f4*>(Lp.W + (16 * MT + p) * LDW + 16 * (kc + j) + 4 * q);
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < K1; ++c) acc[c][MT] = mfma4(a[j][r], B[c][j][r], acc[c][MT]);
+      }
+    }
+    if constexpr (!LAST) {
+      activate<ACT, NTO, K1>(acc);
+#pragma unroll
+      for (int c = 0; c < K1; ++c)
+#pragma unroll
+        for (int MT = 0; MT < NTO; ++MT)
+          *reinterpret_cast<f4*>(Lp.out_act + ((t * K1 + c) * NTO + MT) * 256 + lane * 4) = acc[c][MT];
+    } else {
+      static_assert(!LAST || NTO == 1, "the output layer has one (padded) tile");
+      f4 (&out)[K1][1] = acc;
+      if (P.Y != nullptr && valid) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = 4 * q + r;
+          if (o < P.d_out) {
+            P.Y[pt * P.d_out + o] = out[0][0][r];
+            if (P.dY != nullptr) {
+#pragma unroll
+              for (int c = 1; c < K1; ++c) P.dY[((int64_t)(c - 1) * P.N + pt) * P.d_out + o] = out[c][0][r];
+            }
+          }
+        }
+      }
+      f4 G[K1][1];
+#pragma unroll
+      for (int c = 0; c < K1; ++c) G[c][0] = f4{0.f, 0.f, 0.f, 0.f};
+      if (P.loss_kind == 1) {
+        if (P.residual_id == PINN_RES_NAVIER_STOKES) {
+          if constexpr (K1 >= 4) residual_tile<ResNavierStokes, K1, GRAD>(P, out, G, sums, sm, tb, valid, false, p, q);
+        } else if (P.residual_id == PINN_RES_PHYSICS_EQUATION) {
+          if constexpr (K1 >= 3) residual_tile<ResPhysicsEquation, K1, GRAD>(P, out, G, sums, sm, tb, valid, false, p, q);
+        } else {
+          if constexpr (K1 >= 3) {
+            const bool masked = P.residual_id == PINN_RES_CONTINUITY_ONLY && P.X[ptc * P.d_in + P.xcol] < P.thr;
+            residual_tile<ResContinuity, K1, GRAD>(P, out, G, sums, sm, tb, valid, masked, p, q);
+          }
+        }
+      } else if (P.loss_kind == 2) {
+        float gm[1][PINN_MAX_ROLES];
+#pragma unroll
+        for (int j = 0; j < PINN_MAX_ROLES; ++j) {
+          gm[0][j] = 0.f;
+          if (j < P.n_cols) {
+            const float y = gather_out(out[0][0], P.out_col[j], p);
+            const float d = P.T[ptc * P.n_cols + j] - y;
+            if (valid && q == 0) sums[j] += d * d;
+            if (GRAD) gm[0][j] = -2.f * P.scale[j] * d;
+          }
+        }
+        if constexpr (GRAD) scatter_adjoint<K1, 1, PINN_MAX_ROLES>(tb, gm, sm, G, valid, p, q);
+      }
+      if constexpr (GRAD) {
+#pragma unroll
+        for (int c = 0; c < K1; ++c) *reinterpret_cast<f4*>(Lp.g_out + ((t * K1 + c) * 1 + 0) * 256 + lane * 4) = G[c][0];
+      }
+    }
+  }
+  if constexpr (LAST) {
+#pragma unroll
+    for (int j = 0; j < MAX_SUMS; ++j) {
+      float v = sums[j];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0) lsum[wave * MAX_SUMS + j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < MAX_SUMS) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WIDE_WAVES; ++w) v += lsum[w * MAX_SUMS + threadIdx.x];
+      P.wg_sums[((int64_t)Lp.sums_slot + blockIdx.x) * MAX_SUMS + threadIdx.x] = v;
+    }
+  }
+}
+
+// zbar = adjoint through the activation (HIDDEN; written back over g_in), abar_in = W^T zbar (NEED_GIN).
+// NTK = tiles of the layer OUTPUT (the contraction axis here), NTO = tiles of the layer INPUT.
+template <int NTK, int NTO, int K1, int ACT, bool HIDDEN, bool NEED_GIN>
+__global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_bwd(const FusedParams P, const WideLayer Lp) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = lane & 15, q = lane >> 4;
+  constexpr int CH = NTK < 4 ? NTK : 4;
+  constexpr int LDW = 16 * NTK;
+  const int gw = blockIdx.x * WIDE_WAVES + wave, nw = gridDim.x * WIDE_WAVES;
+  for (int64_t t = gw; t < Lp.n_tiles; t += nw) {
+    f4 acc[K1][NTO];
+    zero_tiles<NTO, K1>(acc);
+    for (int kc = 0; kc < NTK; kc += CH) {
+      f4 g[K1][CH];
+#pragma unroll
+      for (int c = 0; c < K1; ++c)
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+          g[c][j] = *reinterpret_cast<const f4*>(Lp.g_in + ((t * K1 + c) * NTK + kc + j) * 256 + lane * 4);
+      if constexpr (HIDDEN) {
+        f4 ao[K1][CH];
+#pragma unroll
+        for (int c = 0; c < K1; ++c)
+#pragma unroll
+          for (int j = 0; j < CH; ++j)
+            ao[c][j] = *reinterpret_cast<const f4*>(Lp.in_act + ((t * K1 + c) * NTK + kc + j) * 256 + lane * 4);
+        activate_adjoint<ACT, CH, K1>(g, ao);
+#pragma unroll
+        for (int c = 0; c < K1; ++c)
+#pragma unroll
+          for (int j = 0; j < CH; ++j)
+            *reinterpret_cast<f4*>(Lp.g_in + ((t * K1 + c) * NTK + kc + j) * 256 + lane * 4) = g[c][j];
+      }
+      if constexpr (NEED_GIN) {
+#pragma unroll
+        for (int MT = 0; MT < NTO; ++MT) {
+          f4 a[CH];
+#pragma unroll
+          for (int j = 0; j < CH; ++j)
+            a[j] = *reinterpret_cast<const f4*>(Lp.W + (16 * MT + p) * LDW + 16 * (kc + j) + 4 * q);
+#pragma unroll
+          for (int j = 0; j < CH; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int c = 0; c < K1; ++c) acc[c][MT] = mfma4(a[j][r], g[c][j][r], acc[c][MT]);
+        }
+      }
+    }
+    if constexpr (NEED_GIN) {
+#pragma unroll
+      for (int c = 0; c < K1; ++c)
+#pragma unroll
+        for (int MT = 0; MT < NTO; ++MT)
+          *reinterpret_cast<f4*>(Lp.g_out + ((t * K1 + c) * NTO + MT) * 256 + lane * 4) = acc[c][MT];
+    }
+  }
+}
+
+// Split-K weight gradient.  blockIdx.y = row block (MTB output tiles), blockIdx.x*waves = split.
+// NTM = output tiles of the layer, NTN = input tiles.  FIRST: the layer input is (x, tangents).
+template <int MTB, int NTM, int NTN, int K1, bool FIRST>
+__global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_wgrad(const FusedParams P, const WideLayer Lp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = lane & 15, q = lane >> 4;
+  float* tb = smem + wave * (WIDE_MAX_PADS * TB_FLOATS);
+  const int rb = blockIdx.y;
+  f4 dw[MTB][NTN];
+  float bs[MTB];
+#pragma unroll
+  for (int MT = 0; MT < MTB; ++MT) {
+    bs[MT] = 0.f;
+#pragma unroll
+    for (int NT = 0; NT < NTN; ++NT) dw[MT][NT] = f4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int gw = blockIdx.x * WIDE_WAVES + wave, nw = gridDim.x * WIDE_WAVES;
+  for (int64_t t = gw; t < Lp.n_tiles; t += nw) {
+    f4 b0[K1][1];
+    if constexpr (FIRST) {
+      const int64_t pt = (Lp.tile0 + t) * 16 + p;
+      wide_input_jet<K1>(P, pt < P.N ? pt : P.N - 1, q, b0);
+    }
+#pragma unroll
+    for (int c = 0; c < K1; ++c) {
+      f4 zt[MTB], at[NTN];
+#pragma unroll
+      for (int MT = 0; MT < MTB; ++MT)
+        transpose_write(tb + MT * TB_FLOATS,
+                        *reinterpret_cast<const f4*>(Lp.g_in + ((t * K1 + c) * NTM + rb * MTB + MT) * 256 + lane * 4), p, q);
+#pragma unroll
+      for (int NT = 0; NT < NTN; ++NT) {
+        f4 av;
+        if constexpr (FIRST) av = b0[c][0];
+        else av = *reinterpret_cast<const f4*>(Lp.in_act + ((t * K1 + c) * NTN + NT) * 256 + lane * 4);
+        transpose_write(tb + (4 + NT) * TB_FLOATS, av, p, q);
+      }
+#pragma unroll
+      for (int MT = 0; MT < MTB; ++MT) zt[MT] = transpose_read(tb + MT * TB_FLOATS, p, q);
+#pragma unroll
+      for (int NT = 0; NT < NTN; ++NT) at[NT] = transpose_read(tb + (4 + NT) * TB_FLOATS, p, q);
+      if (c == 0) {
+#pragma unroll
+        for (int MT = 0; MT < MTB; ++MT) bs[MT] += (zt[MT][0] + zt[MT][1]) + (zt[MT][2] + zt[MT][3]);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int MT = 0; MT < MTB; ++MT)
+#pragma unroll
+          for (int NT = 0; NT < NTN; ++NT) dw[MT][NT] = mfma4(zt[MT][s], at[NT][s], dw[MT][NT]);
+    }
+  }
+  // one flush per wave into the flat torch-layout gradient (out_d x in_d row-major)
+#pragma unroll
+  for (int MT = 0; MT < MTB; ++MT) {
+#pragma unroll
+    for (int NT = 0; NT < NTN; ++NT)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * (rb * MTB + MT) + 4 * q + r, col = 16 * NT + p;
+        if (row < Lp.out_d && col < Lp.in_d)
+          __hip_atomic_fetch_add(Lp.dW + (int64_t)row * Lp.in_d + col, dw[MT][NT][r], __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+      }
+    float t = bs[MT];
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    const int row = 16 * (rb * MTB + MT) + p;
+    if (q == 0 && row < Lp.out_d)
+      __hip_atomic_fetch_add(Lp.db + row, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// launchers, one translation unit per padded width (pinn_wide_w128.hip / _w256.hip)
+template <int NTW>
+int launch_wide_fwd(int which /*0 first, 1 hidden, 2 last*/, int K1, int act, bool grad, const FusedParams& P,
+                    const WideLayer& Lp, int grid, hipStream_t s);
+template <int NTW>
+int launch_wide_bwd(int which /*0 first, 1 hidden, 2 last*/, int K1, int act, const FusedParams& P, const WideLayer& Lp,
+                    int grid, hipStream_t s);
+template <int NTW>
+int launch_wide_wgrad(int which /*0 first, 1 hidden, 2 last*/, int K1, const FusedParams& P, const WideLayer& Lp,
+                      int grid_x, hipStream_t s);
+
+}  // namespace pinn

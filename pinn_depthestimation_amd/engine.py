@@ -13,7 +13,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import (ACT_LEAKY_RELU, ACT_TANH, ENGINE_AUTO, ENGINE_FUSED, ENGINE_GENERIC, RES_CONTINUITY_FTEMP,
+from ._lib import (ACT_LEAKY_RELU, ACT_TANH, ENGINE_AUTO, ENGINE_FUSED, ENGINE_GENERIC, ENGINE_WIDE, RES_CONTINUITY_FTEMP,
                    RES_CONTINUITY_ONLY, RES_NAVIER_STOKES, RES_PHYSICS_EQUATION, RES_TERMS, PinnDesc, PinnError,
                    PinnResidualSpec, check)
 

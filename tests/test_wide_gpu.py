@@ -1,0 +1,93 @@
+"""Parity of the wide MFMA engine (64 < hidden width <= 256, one launch per layer — the shape
+class of BASELINE configs[3], 12 x 256) against the fp64 oracle and the generic engine."""
+import pytest
+import torch
+
+from oracle import pinn_oracle as O
+from pinn_depthestimation_amd import Engine, NetDesc, ResidualSpec
+from pinn_depthestimation_amd._lib import ENGINE_GENERIC, ENGINE_WIDE
+from tests.test_engine_gpu import oracle_loss_and_grad, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "ns_3x128": (3, 4, 3, 128, (0, 1, 2), "Navier_Stokes", ("t", "x", "y"), ("h", "z", "u", "v")),
+    "ns_2x256": (3, 4, 2, 256, (0, 1, 2), "Navier_Stokes", ("t", "x", "y"), ("h", "z", "u", "v")),
+    "pe_3x100": (2, 6, 3, 100, (0, 1), "physics_equation", ("x", "y"), ("h", "U", "V", "eta_mean", "Hrms", "k")),
+    "co_2x200": (2, 3, 2, 200, (0, 1), "continuity_only", ("x", "y"), ("U", "V", "h")),
+}
+
+
+def make(name, N, seed=4321):
+    d_in, d_out, L, W, gc, res, inn, outn = CASES[name]
+    g = torch.Generator().manual_seed(seed)
+    params = O.init_params(O.layer_sizes(d_in, L, W, d_out), "xavier", g)
+    if res == "physics_equation":
+        params[-1][outn.index("h")] = 0.75
+        params[-1][outn.index("eta_mean")] = 0.0
+    X = torch.rand(N, d_in, generator=g) * 2 - 1
+    return params, X, NetDesc(d_in, d_out, L, W, gc), res, inn, outn
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_wide_loss_grad_and_jet(name):
+    N = 1237
+    params, X, desc, res, inn, outn = make(name, N)
+    if res == "continuity_only":
+        X[:, 0] = X[:, 0] * 40
+    eng = Engine(desc.with_(engine=ENGINE_WIDE))
+    flat, Xd = O.flatten(params).cuda(), X.cuda().contiguous()
+    spec = ResidualSpec.from_names(res, inn, desc.grad_cols, outn)
+    l64, g64 = oracle_loss_and_grad(params, X, res, inn, outn, desc.grad_cols, torch.float64)
+    l32, g32 = oracle_loss_and_grad(params, X, res, inn, outn, desc.grad_cols, torch.float32)
+    if res == "continuity_only":
+        cnt = float((X[:, 0] < 25.5).sum())
+        scale = torch.tensor([1.0 / N, 1.0 / cnt, 0.0])
+    else:
+        scale = torch.full((spec.n_terms,), 1.0 / N)
+    grad = torch.zeros(desc.n_params, device="cuda")
+    sums = eng.residual_loss_grad(spec, scale.cuda(), flat, Xd, grad)
+    loss = float((sums.cpu().double() * scale.double()).sum())
+    assert abs(loss - float(l64)) / abs(float(l64)) < max(3e-6, 4 * abs(float(l32) - float(l64)) / abs(float(l64)))
+    assert rel_l2(grad.cpu(), g64) < max(3e-5, 4 * rel_l2(g32, g64))
+    assert torch.allclose(eng.residual_loss(spec, flat, Xd), sums, rtol=1e-6)
+    Y, dY = eng.forward_jet(flat, Xd)
+    Yo, dYo = O.jet([p.double() for p in params], X.double(), desc.grad_cols)
+    assert (Y.cpu().double() - Yo).abs().max() < 3e-6
+    assert (dY.cpu().double() - dYo).abs().max() < 3e-6 * max(1.0, float(dYo.abs().max()))
+    assert (eng.forward(flat, Xd).cpu().double() - Yo).abs().max() < 3e-6
+
+
+def test_wide_mse_and_auto_dispatch():
+    params, X, desc, *_ = make("ns_3x128", 50)
+    g = torch.Generator().manual_seed(2)
+    T = torch.rand(50, 2, generator=g)
+    p = [q.double().requires_grad_(True) for q in params]
+    lo = O.fidelity_loss(p, X.double(), T.double(), [2, 0], [1.0, 3.0])
+    go = O.flat_grad(lo, p)
+    eng = Engine(desc)                                     # AUTO must pick the wide engine for width 128
+    scale = torch.tensor([1.0, 3.0]) / 50
+    grad = torch.zeros(desc.n_params, device="cuda")
+    sums = eng.mse_loss_grad(O.flatten(params).cuda(), X.cuda(), T.cuda(), [2, 0], scale.cuda(), grad)
+    assert abs(float((sums.cpu().double() * scale.double()).sum()) - float(lo)) / float(lo) < 3e-6
+    assert rel_l2(grad.cpu(), go) < 3e-5
+    gen = Engine(desc.with_(engine=ENGINE_GENERIC))
+    grad2 = torch.zeros(desc.n_params, device="cuda")
+    gen.mse_loss_grad(O.flatten(params).cuda(), X.cuda(), T.cuda(), [2, 0], scale.cuda(), grad2)
+    assert rel_l2(grad.cpu(), grad2.cpu()) < 3e-5
+
+
+def test_wide_chunked_12x256_matches_generic():
+    """BASELINE configs[3] shape; enough points that the host loop runs several chunks."""
+    desc = NetDesc(3, 4, 12, 256, (0, 1, 2))
+    g = torch.Generator().manual_seed(11)
+    params = O.flatten(O.init_params(desc.layers, "xavier", g)).cuda()
+    N = 120_011
+    X = (torch.rand(N, 3, generator=g) * 2 - 1).cuda()
+    spec = ResidualSpec.from_names("Navier_Stokes", ("t", "x", "y"), desc.grad_cols, ("h", "z", "u", "v"))
+    scale = torch.full((3,), 1.0 / N, device="cuda")
+    gw, gg = torch.zeros(desc.n_params, device="cuda"), torch.zeros(desc.n_params, device="cuda")
+    sw = Engine(desc.with_(engine=ENGINE_WIDE)).residual_loss_grad(spec, scale, params, X, gw)
+    sg = Engine(desc.with_(engine=ENGINE_GENERIC)).residual_loss_grad(spec, scale, params, X, gg)
+    assert torch.allclose(sw, sg, rtol=3e-5)
+    assert rel_l2(gw.cpu(), gg.cpu()) < 3e-5
