@@ -40,9 +40,11 @@ WLayout wlayout(const Net& n, const WGeo& g, int64_t N) {
   WLayout w;
   const int K1 = 1 + PINN_MAX_DIRS;
   const int64_t per_pt = (int64_t)K1 * g.WP * 4 * (n.L + 2) + (int64_t)K1 * 16 * 4;
+  // whole number of tiles per wave in every full chunk (no tail imbalance): multiple of waves * 16 points
+  const int64_t quantum = (int64_t)cus() * WIDE_WAVES * 16;
   int64_t cp = ACT_BUDGET_BYTES / per_pt;
-  cp = (cp / 4096) * 4096;
-  if (cp < 4096) cp = 4096;
+  cp = (cp / quantum) * quantum;
+  if (cp < quantum) cp = quantum;
   const int64_t npad = ((N + 15) / 16) * 16;
   if (cp > npad) cp = npad;
   w.chunk_pts = cp; w.chunk_tiles = cp / 16; w.n_chunks = (npad + cp - 1) / cp;
