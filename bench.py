@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--points", type=int, default=PTS_PER_GPU, help="points per GPU")
     ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 generic, 2 fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bf16", action="store_true", help="bf16 MFMA operands (wide engine only; extra evidence)")
     ap.add_argument("--workload", default="ns8x64", choices=sorted(WORKLOADS),
                     help="default = the headline BASELINE configs[1]; others are extra evidence, not the contract line")
     args = ap.parse_args()
@@ -117,7 +118,7 @@ def main():
     from pinn_depthestimation_amd.dnn import init_flat_params
 
     d_in, d_out, hidden, width, gcols, res_name, in_names, out_names, flop_pt = WORKLOADS[args.workload]
-    desc = NetDesc(d_in, d_out, hidden, width, gcols, engine=args.engine)
+    desc = NetDesc(d_in, d_out, hidden, width, gcols, engine=args.engine, precision=1 if args.bf16 else 0)
     spec = ResidualSpec.from_names(res_name, in_names, desc.grad_cols, out_names)
     eng = Engine(desc, dev)
     P = desc.n_params
@@ -189,7 +190,7 @@ def main():
             "value": n_global * args.steps / dt, "unit": "residual-points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if args.bf16 else "f32", "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[1]: " if args.workload == "ns8x64" else f"[{args.workload}] ") +
                                    f"{d_in}->{hidden}x{width} tanh->{d_out} MLP, {res_name} residual, "
                                    f"{N} synthetic ({','.join(in_names)}) points per GPU, full-batch Adam step",

@@ -57,6 +57,11 @@ extern "C" {
 #define PINN_ENGINE_FUSED 2    /* MFMA chain kernel, one persistent launch, hidden width <= 64 */
 #define PINN_ENGINE_WIDE 3     /* MFMA chain, one launch per layer, 64 < hidden width <= 256 */
 
+/* GEMM operand precision.  Everything outside the MFMAs (tanh, residual, adjoints, gradient
+ * accumulation, Adam) is fp32 in both modes. */
+#define PINN_PREC_F32 0   /* v_mfma_f32_16x16x4_f32: exact fp32 (the reference's precision) */
+#define PINN_PREC_BF16 1  /* v_mfma_f32_16x16x16_bf16: bf16 operands, fp32 accumulate (BASELINE configs[3]); wide engine only */
+
 /* error codes */
 #define PINN_OK 0
 #define PINN_ERR_INVALID (-1)
@@ -73,6 +78,7 @@ typedef struct pinn_desc {
   int32_t dir_col[PINN_MAX_DIRS]; /* X column of tangent direction j */
   int32_t activation; /* PINN_ACT_* */
   int32_t engine;     /* PINN_ENGINE_* */
+  int32_t precision;  /* PINN_PREC_*: operand type of the weight GEMMs */
 } pinn_desc;
 
 /* residual ids */

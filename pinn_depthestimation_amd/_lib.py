@@ -15,6 +15,7 @@ PINN_MAX_ROLES = 8
 
 ACT_TANH, ACT_LEAKY_RELU = 0, 1
 ENGINE_AUTO, ENGINE_GENERIC, ENGINE_FUSED, ENGINE_WIDE = 0, 1, 2, 3
+PREC_F32, PREC_BF16 = 0, 1
 
 RES_NAVIER_STOKES, RES_PHYSICS_EQUATION, RES_CONTINUITY_FTEMP, RES_CONTINUITY_ONLY = 1, 2, 3, 4
 RES_TERMS = {RES_NAVIER_STOKES: 3, RES_PHYSICS_EQUATION: 3, RES_CONTINUITY_FTEMP: 1, RES_CONTINUITY_ONLY: 3}
@@ -24,7 +25,7 @@ class PinnDesc(C.Structure):
     _fields_ = [
         ("d_in", C.c_int32), ("d_out", C.c_int32), ("n_hidden", C.c_int32), ("width", C.c_int32),
         ("k", C.c_int32), ("dir_col", C.c_int32 * PINN_MAX_DIRS),
-        ("activation", C.c_int32), ("engine", C.c_int32),
+        ("activation", C.c_int32), ("engine", C.c_int32), ("precision", C.c_int32),
     ]
 
 

@@ -12,7 +12,7 @@ void set_error(const char* fmt, ...);
 
 // layer geometry helpers: layers = [d_in] + [width]*n_hidden + [d_out] (train.py:56)
 struct Net {
-  int d_in, d_out, L /*hidden layers*/, W, k, K1, act;
+  int d_in, d_out, L /*hidden layers*/, W, k, K1, act, prec;
   int dir_col[PINN_MAX_DIRS];
   int n_lin;  // L + 1 linear layers
   __host__ __device__ int in_dim(int l) const { return l == 0 ? d_in : W; }

@@ -210,11 +210,12 @@ __device__ __forceinline__ float row_sum16(float v) {
 __device__ __forceinline__ void transpose_write(float* __restrict__ tb, f4 v, int p, int q) {
   *reinterpret_cast<f4*>(tb + p * 16 + 4 * (q ^ (p & 3))) = v;
 }
+template <bool CONSECUTIVE = false>   // false: element s <-> point 4s + q ; true: element s <-> point 4q + s
 __device__ __forceinline__ f4 transpose_read(const float* __restrict__ tb, int p, int q) {
   f4 o;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const int pt = 4 * s + q;                               // point index of this k-step for lane group q
+    const int pt = CONSECUTIVE ? 4 * q + s : 4 * s + q;     // point index of element s for lane group q
     o[s] = tb[pt * 16 + 4 * ((p >> 2) ^ (pt & 3)) + (p & 3)];   // feature p of that point
   }
   return o;

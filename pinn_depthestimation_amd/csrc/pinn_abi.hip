@@ -28,6 +28,10 @@ int make_net(const pinn_desc* d, Net* n) {
   }
   n->d_in = d->d_in; n->d_out = d->d_out; n->L = d->n_hidden; n->W = d->width;
   n->k = d->k; n->K1 = 1 + d->k; n->act = d->activation; n->n_lin = d->n_hidden + 1;
+  if (d->precision != PINN_PREC_F32 && d->precision != PINN_PREC_BF16) {
+    set_error("invalid precision %d", d->precision); return PINN_ERR_INVALID;
+  }
+  n->prec = d->precision;
   for (int j = 0; j < PINN_MAX_DIRS; ++j) {
     n->dir_col[j] = j < d->k ? d->dir_col[j] : -1;
     if (j < d->k && (d->dir_col[j] < 0 || d->dir_col[j] >= d->d_in)) {
@@ -41,6 +45,13 @@ int make_net(const pinn_desc* d, Net* n) {
 // 1 = generic, 2 = fused, 3 = wide
 static int pick_engine(const pinn_desc* d, const Net& n, int* rc) {
   *rc = PINN_OK;
+  if (n.prec == PINN_PREC_BF16) {   // bf16 operands exist on the wide engine only
+    if ((d->engine != PINN_ENGINE_AUTO && d->engine != PINN_ENGINE_WIDE) || !wide_supports(n)) {
+      set_error("precision bf16 is implemented on the wide engine (64 < width <= 256, tanh, k in {0,2,3}) only");
+      *rc = PINN_ERR_UNSUPPORTED;
+    }
+    return PINN_ENGINE_WIDE;
+  }
   if (d->engine == PINN_ENGINE_GENERIC) return PINN_ENGINE_GENERIC;
   if (d->engine == PINN_ENGINE_FUSED || d->engine == PINN_ENGINE_WIDE) {
     const bool ok = d->engine == PINN_ENGINE_FUSED ? fused_supports(n) : wide_supports(n);

@@ -33,7 +33,7 @@ constexpr int64_t ACT_BUDGET_BYTES = (int64_t)6 << 30;   // activation workspace
 
 struct WLayout {
   int64_t chunk_pts, chunk_tiles, n_chunks;
-  int64_t wp, wtp, bp, act, act_stride, gA, gB, gout, sums, total;
+  int64_t wp, wtp, bp, wp16, wtp16, act, act_stride, gA, gB, gout, sums, total;
   int grid;
 };
 WLayout wlayout(const Net& n, const WGeo& g, int64_t N) {
@@ -53,6 +53,8 @@ WLayout wlayout(const Net& n, const WGeo& g, int64_t N) {
   w.wp = off; off += al256((int64_t)g.PW * 4);
   w.wtp = off; off += al256((int64_t)g.PW * 4);
   w.bp = off; off += al256((int64_t)g.PB * 4);
+  w.wp16 = off; off += al256((int64_t)g.PW * 2);
+  w.wtp16 = off; off += al256((int64_t)g.PW * 2);
   w.act_stride = al256(w.chunk_tiles * K1 * g.NTW * 256 * 4);
   w.act = off; off += w.act_stride * n.L;
   w.gA = off; off += w.act_stride;
@@ -63,8 +65,11 @@ WLayout wlayout(const Net& n, const WGeo& g, int64_t N) {
   return w;
 }
 
+__device__ inline unsigned short bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+
 __global__ void k_wide_pack(Net n, int WP, const float* __restrict__ params, float* __restrict__ Wp,
-                            float* __restrict__ WTp, float* __restrict__ Bp, int PW, int PB) {
+                            float* __restrict__ WTp, float* __restrict__ Bp, unsigned short* __restrict__ Wp16,
+                            unsigned short* __restrict__ WTp16, int PW, int PB) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < PW) {
     int l, rem;
@@ -74,9 +79,11 @@ __global__ void k_wide_pack(Net n, int WP, const float* __restrict__ params, flo
     const int in_d = n.in_dim(l), out_d = n.out_dim(l);
     const int base = i - rem;
     { const int o = rem / inP, c = rem % inP;
-      Wp[i] = (o < out_d && c < in_d) ? params[n.w_off(l) + (int64_t)o * in_d + c] : 0.f; }
+      const float v = (o < out_d && c < in_d) ? params[n.w_off(l) + (int64_t)o * in_d + c] : 0.f;
+      Wp[i] = v; Wp16[i] = bf16_bits(v); }
     { const int c = rem / outP, o = rem % outP;
-      WTp[base + rem] = (o < out_d && c < in_d) ? params[n.w_off(l) + (int64_t)o * in_d + c] : 0.f; }
+      const float v = (o < out_d && c < in_d) ? params[n.w_off(l) + (int64_t)o * in_d + c] : 0.f;
+      WTp[base + rem] = v; WTp16[base + rem] = bf16_bits(v); }
   }
   if (i < PB) {
     int l = i / WP, o = i % WP;
@@ -123,9 +130,13 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
   const float* Wp = (const float*)(base + w.wp);
   const float* WTp = (const float*)(base + w.wtp);
   const float* Bp = (const float*)(base + w.bp);
+  const unsigned short* Wp16 = (const unsigned short*)(base + w.wp16);
+  const unsigned short* WTp16 = (const unsigned short*)(base + w.wtp16);
+  const int prec = n.prec;
   const int packN = g.PW > g.PB ? g.PW : g.PB;
   hipLaunchKernelGGL(k_wide_pack, dim3((packN + 255) / 256), dim3(256), 0, s, n, g.WP, params, (float*)(base + w.wp),
-                     (float*)(base + w.wtp), (float*)(base + w.bp), g.PW, g.PB);
+                     (float*)(base + w.wtp), (float*)(base + w.bp), (unsigned short*)(base + w.wp16),
+                     (unsigned short*)(base + w.wtp16), g.PW, g.PB);
   auto woff = [&](int l) { return l == 0 ? 0 : g.WP * 16 + (l - 1) * g.WP * g.WP; };
   auto act_l = [&](int l) { return (float*)(base + w.act + (int64_t)(l - 1) * w.act_stride); };   // a_l, l = 1..L
   float* gA = (float*)(base + w.gA);
@@ -147,40 +158,40 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
       set_error("hipMemsetAsync failed"); return PINN_ERR_LAUNCH;
     }
     // ---- forward ----
-    Lp.W = Wp; Lp.b = Bp; Lp.out_act = act_l(1);
-    rc = launch_wide_fwd<NTW>(0, K1, n.act, false, P, Lp, grid, s); if (rc) break;
+    Lp.W = Wp; Lp.W16 = Wp16; Lp.b = Bp; Lp.out_act = act_l(1);
+    rc = launch_wide_fwd<NTW>(0, K1, prec, false, P, Lp, grid, s); if (rc) break;
     for (int l = 1; l < L; ++l) {
-      Lp.W = Wp + woff(l); Lp.b = Bp + l * g.WP; Lp.in_act = act_l(l); Lp.out_act = act_l(l + 1);
-      rc = launch_wide_fwd<NTW>(1, K1, n.act, false, P, Lp, grid, s); if (rc) break;
+      Lp.W = Wp + woff(l); Lp.W16 = Wp16 + woff(l); Lp.b = Bp + l * g.WP; Lp.in_act = act_l(l); Lp.out_act = act_l(l + 1);
+      rc = launch_wide_fwd<NTW>(1, K1, prec, false, P, Lp, grid, s); if (rc) break;
     }
     if (rc) break;
-    Lp.W = Wp + woff(L); Lp.b = Bp + L * g.WP; Lp.in_act = act_l(L); Lp.out_act = nullptr; Lp.g_out = gout;
-    rc = launch_wide_fwd<NTW>(2, K1, n.act, grad, P, Lp, grid, s); if (rc) break;
+    Lp.W = Wp + woff(L); Lp.W16 = Wp16 + woff(L); Lp.b = Bp + L * g.WP; Lp.in_act = act_l(L); Lp.out_act = nullptr; Lp.g_out = gout;
+    rc = launch_wide_fwd<NTW>(2, K1, prec, grad, P, Lp, grid, s); if (rc) break;
     if (!grad) continue;
     // ---- reverse sweep ----
-    const int gx_h = w.grid / (NTW / 4) > 0 ? w.grid / (NTW / 4) : 1;
+    const int gx_h = w.grid;   // row blocks are waves of a workgroup now; one workgroup per CU
     // output layer: dW_L = G . a_L^T ; abar_L = W_L^T G
     Lp.g_in = gout; Lp.in_act = act_l(L); Lp.in_d = n.in_dim(L); Lp.out_d = n.out_dim(L);
     Lp.dW = rq->grad + n.w_off(L); Lp.db = rq->grad + n.b_off(L);
-    rc = launch_wide_wgrad<NTW>(2, K1, P, Lp, w.grid, s); if (rc) break;
-    Lp.W = WTp + woff(L); Lp.g_out = gA;
-    rc = launch_wide_bwd<NTW>(2, K1, n.act, P, Lp, grid, s); if (rc) break;
+    rc = launch_wide_wgrad<NTW>(2, K1, prec, P, Lp, w.grid, s); if (rc) break;
+    Lp.W = WTp + woff(L); Lp.W16 = WTp16 + woff(L); Lp.g_out = gA;
+    rc = launch_wide_bwd<NTW>(2, K1, prec, P, Lp, grid, s); if (rc) break;
     float* gcur = gA; float* gnext = gB;
     for (int l = L - 1; l >= 1; --l) {
       // zbar_l (in place over gcur) and abar_l = W_l^T zbar_l
-      Lp.W = WTp + woff(l); Lp.g_in = gcur; Lp.in_act = act_l(l + 1); Lp.g_out = gnext;
-      rc = launch_wide_bwd<NTW>(1, K1, n.act, P, Lp, grid, s); if (rc) break;
+      Lp.W = WTp + woff(l); Lp.W16 = WTp16 + woff(l); Lp.g_in = gcur; Lp.in_act = act_l(l + 1); Lp.g_out = gnext;
+      rc = launch_wide_bwd<NTW>(1, K1, prec, P, Lp, grid, s); if (rc) break;
       Lp.in_act = act_l(l); Lp.in_d = n.in_dim(l); Lp.out_d = n.out_dim(l);
       Lp.dW = rq->grad + n.w_off(l); Lp.db = rq->grad + n.b_off(l);
-      rc = launch_wide_wgrad<NTW>(1, K1, P, Lp, gx_h, s); if (rc) break;
+      rc = launch_wide_wgrad<NTW>(1, K1, prec, P, Lp, gx_h, s); if (rc) break;
       float* t = gcur; gcur = gnext; gnext = t;
     }
     if (rc) break;
     Lp.g_in = gcur; Lp.in_act = act_l(1); Lp.g_out = nullptr; Lp.W = nullptr;
-    rc = launch_wide_bwd<NTW>(0, K1, n.act, P, Lp, grid, s); if (rc) break;
+    rc = launch_wide_bwd<NTW>(0, K1, prec, P, Lp, grid, s); if (rc) break;
     Lp.in_act = nullptr; Lp.in_d = n.in_dim(0); Lp.out_d = n.out_dim(0);
     Lp.dW = rq->grad + n.w_off(0); Lp.db = rq->grad + n.b_off(0);
-    rc = launch_wide_wgrad<NTW>(0, K1, P, Lp, gx_h, s); if (rc) break;
+    rc = launch_wide_wgrad<NTW>(0, K1, prec, P, Lp, gx_h, s); if (rc) break;
   }
   if (rc) return rc;
   if (rq) {

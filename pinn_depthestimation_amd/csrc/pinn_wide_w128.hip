@@ -17,60 +17,64 @@ static int go(K kern, const FusedParams& P, const WideLayer& Lp, dim3 grid, size
   return check_launch(what);
 }
 
-template <int K1>
+template <int K1, bool BF>
+// only the hidden (W x W) layers take bf16 operands; the thin first/last layers stay fp32
 static int fwd_k(int which, bool grad, const FusedParams& P, const WideLayer& Lp, int grid, hipStream_t s) {
   constexpr int A = PINN_ACT_TANH;
   switch (which) {
-    case 0: return go(k_wide_fwd<1, NTW_, K1, A, true, false, false>, P, Lp, dim3(grid), 0, s, "wide fwd first");
-    case 1: return go(k_wide_fwd<NTW_, NTW_, K1, A, false, false, false>, P, Lp, dim3(grid), 0, s, "wide fwd hidden");
+    case 0: return go(k_wide_fwd<1, NTW_, K1, A, true, false, false, false>, P, Lp, dim3(grid), 0, s, "wide fwd first");
+    case 1: return go(k_wide_fwd<NTW_, NTW_, K1, A, false, false, false, BF>, P, Lp, dim3(grid), 0, s, "wide fwd hidden");
     default:
-      return grad ? go(k_wide_fwd<NTW_, 1, K1, A, false, true, true>, P, Lp, dim3(grid), PADS_LDS, s, "wide fwd last")
-                  : go(k_wide_fwd<NTW_, 1, K1, A, false, true, false>, P, Lp, dim3(grid), PADS_LDS, s, "wide fwd last");
+      return grad ? go(k_wide_fwd<NTW_, 1, K1, A, false, true, true, false>, P, Lp, dim3(grid), PADS_LDS, s, "wide fwd last")
+                  : go(k_wide_fwd<NTW_, 1, K1, A, false, true, false, false>, P, Lp, dim3(grid), PADS_LDS, s, "wide fwd last");
   }
 }
 template <>
-int launch_wide_fwd<NTW_>(int which, int K1, int, bool grad, const FusedParams& P, const WideLayer& Lp, int grid, hipStream_t s) {
+int launch_wide_fwd<NTW_>(int which, int K1, int prec, bool grad, const FusedParams& P, const WideLayer& Lp, int grid, hipStream_t s) {
+  const bool bf = prec == PINN_PREC_BF16;
   switch (K1) {
-    case 1: return fwd_k<1>(which, grad, P, Lp, grid, s);
-    case 3: return fwd_k<3>(which, grad, P, Lp, grid, s);
-    case 4: return fwd_k<4>(which, grad, P, Lp, grid, s);
+    case 1: return bf ? fwd_k<1, true>(which, grad, P, Lp, grid, s) : fwd_k<1, false>(which, grad, P, Lp, grid, s);
+    case 3: return bf ? fwd_k<3, true>(which, grad, P, Lp, grid, s) : fwd_k<3, false>(which, grad, P, Lp, grid, s);
+    case 4: return bf ? fwd_k<4, true>(which, grad, P, Lp, grid, s) : fwd_k<4, false>(which, grad, P, Lp, grid, s);
   }
   set_error("wide engine: no kernel for K1=%d", K1); return PINN_ERR_UNSUPPORTED;
 }
 
-template <int K1>
+template <int K1, bool BF>
 static int bwd_k(int which, const FusedParams& P, const WideLayer& Lp, int grid, hipStream_t s) {
   constexpr int A = PINN_ACT_TANH;
   switch (which) {
-    case 0: return go(k_wide_bwd<NTW_, 1, K1, A, true, false>, P, Lp, dim3(grid), 0, s, "wide bwd first");
-    case 1: return go(k_wide_bwd<NTW_, NTW_, K1, A, true, true>, P, Lp, dim3(grid), 0, s, "wide bwd hidden");
-    default: return go(k_wide_bwd<1, NTW_, K1, A, false, true>, P, Lp, dim3(grid), 0, s, "wide bwd last");
+    case 0: return go(k_wide_bwd<NTW_, 1, K1, A, true, false, false>, P, Lp, dim3(grid), 0, s, "wide bwd first");
+    case 1: return go(k_wide_bwd<NTW_, NTW_, K1, A, true, true, BF>, P, Lp, dim3(grid), 0, s, "wide bwd hidden");
+    default: return go(k_wide_bwd<1, NTW_, K1, A, false, true, false>, P, Lp, dim3(grid), 0, s, "wide bwd last");
   }
 }
 template <>
-int launch_wide_bwd<NTW_>(int which, int K1, int, const FusedParams& P, const WideLayer& Lp, int grid, hipStream_t s) {
+int launch_wide_bwd<NTW_>(int which, int K1, int prec, const FusedParams& P, const WideLayer& Lp, int grid, hipStream_t s) {
+  const bool bf = prec == PINN_PREC_BF16;
   switch (K1) {
-    case 1: return bwd_k<1>(which, P, Lp, grid, s);
-    case 3: return bwd_k<3>(which, P, Lp, grid, s);
-    case 4: return bwd_k<4>(which, P, Lp, grid, s);
+    case 1: return bf ? bwd_k<1, true>(which, P, Lp, grid, s) : bwd_k<1, false>(which, P, Lp, grid, s);
+    case 3: return bf ? bwd_k<3, true>(which, P, Lp, grid, s) : bwd_k<3, false>(which, P, Lp, grid, s);
+    case 4: return bf ? bwd_k<4, true>(which, P, Lp, grid, s) : bwd_k<4, false>(which, P, Lp, grid, s);
   }
   set_error("wide engine: no kernel for K1=%d", K1); return PINN_ERR_UNSUPPORTED;
 }
 
-template <int K1>
+template <int K1, bool BF>
 static int wg_k(int which, const FusedParams& P, const WideLayer& Lp, int gx, hipStream_t s) {
   switch (which) {
-    case 0: return go(k_wide_wgrad<4, NTW_, 1, K1, true>, P, Lp, dim3(gx, NTW_ / 4), PADS_LDS, s, "wide wgrad first");
-    case 1: return go(k_wide_wgrad<4, NTW_, NTW_, K1, false>, P, Lp, dim3(gx, NTW_ / 4), PADS_LDS, s, "wide wgrad hidden");
-    default: return go(k_wide_wgrad<1, 1, NTW_, K1, false>, P, Lp, dim3(gx, 1), PADS_LDS, s, "wide wgrad last");
+    case 0: return go(k_wide_wgrad<4, NTW_, 1, K1, true, false>, P, Lp, dim3(gx), PADS_LDS, s, "wide wgrad first");
+    case 1: return go(k_wide_wgrad<4, NTW_, NTW_, K1, false, BF>, P, Lp, dim3(gx), PADS_LDS, s, "wide wgrad hidden");
+    default: return go(k_wide_wgrad<1, 1, NTW_, K1, false, false>, P, Lp, dim3(gx), PADS_LDS, s, "wide wgrad last");
   }
 }
 template <>
-int launch_wide_wgrad<NTW_>(int which, int K1, const FusedParams& P, const WideLayer& Lp, int gx, hipStream_t s) {
+int launch_wide_wgrad<NTW_>(int which, int K1, int prec, const FusedParams& P, const WideLayer& Lp, int gx, hipStream_t s) {
+  const bool bf = prec == PINN_PREC_BF16;
   switch (K1) {
-    case 1: return wg_k<1>(which, P, Lp, gx, s);
-    case 3: return wg_k<3>(which, P, Lp, gx, s);
-    case 4: return wg_k<4>(which, P, Lp, gx, s);
+    case 1: return bf ? wg_k<1, true>(which, P, Lp, gx, s) : wg_k<1, false>(which, P, Lp, gx, s);
+    case 3: return bf ? wg_k<3, true>(which, P, Lp, gx, s) : wg_k<3, false>(which, P, Lp, gx, s);
+    case 4: return bf ? wg_k<4, true>(which, P, Lp, gx, s) : wg_k<4, false>(which, P, Lp, gx, s);
   }
   set_error("wide engine: no kernel for K1=%d", K1); return PINN_ERR_UNSUPPORTED;
 }

@@ -26,6 +26,7 @@ constexpr int WIDE_MAX_PADS = 20;   // 4 zbar tiles + 16 input tiles of one quan
 
 struct WideLayer {
   const float* W;        // this layer's padded weights, row-major [16*NTO][16*NTI] (fwd) or W^T (bwd)
+  const unsigned short* W16;  // the same matrix in bf16 (BF16 kernels)
   const float* b;        // padded bias (fwd)
   const float* in_act;   // fwd: layer input jet; bwd: a_{l+1} (layer output jet); wgrad: layer input jet
   float* out_act;        // fwd: layer output jet
@@ -38,6 +39,66 @@ struct WideLayer {
   int64_t n_tiles;       // tiles in this chunk
   int sums_slot;         // row offset in wg_sums for this chunk
 };
+
+// ---- bf16 operands (PINN_PREC_BF16): v_mfma_f32_16x16x16_bf16 takes k = 4*(lane>>4) + j, j = 0..3,
+// per lane — exactly the 4 registers of one accumulator tile (B operand) and 8 contiguous bytes of
+// a bf16 weight row (A operand).  Accumulation stays fp32.
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x4 to_bf16x4(f4 v) {
+  typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+  bf4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};   // v_cvt_pk_bf16_f32 (RNE, NaN-safe)
+  return __builtin_bit_cast(bf16x4, b);
+}
+__device__ __forceinline__ f4 mfma_bf16(bf16x4 a, bf16x4 b, f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x4 load_w16(const unsigned short* __restrict__ W16, int idx) {
+  return *reinterpret_cast<const bf16x4*>(W16 + idx);
+}
+
+// acc[c][MT] += W[16MT + m][16(kc+j) ..] . B[c][j] for every output tile MT of one input chunk.
+// The weight fragments of tile MT+1 are requested before the MFMAs of tile MT issue (one wave per
+// SIMD: an L2 round trip per output tile would otherwise sit exposed 16 times per chunk).
+template <int CH, int K1, int NTO, bool BF16>
+__device__ __forceinline__ void wide_mac_chunk(const WideLayer& Lp, int kc, int ldw, int p, int q, const f4 (&B)[K1][CH],
+                                               f4 (&acc)[K1][NTO]) {
+  if constexpr (BF16) {
+    bf16x4 B16[K1][CH];
+#pragma unroll
+    for (int c = 0; c < K1; ++c)
+#pragma unroll
+      for (int j = 0; j < CH; ++j) B16[c][j] = to_bf16x4(B[c][j]);
+    // (no look-ahead here: measured 12 % slower in bf16 mode, where the MFMA block per tile is short)
+#pragma unroll
+    for (int MT = 0; MT < NTO; ++MT) {
+      bf16x4 a[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) a[j] = load_w16(Lp.W16, (16 * MT + p) * ldw + 16 * (kc + j) + 4 * q);
+#pragma unroll
+      for (int j = 0; j < CH; ++j)
+#pragma unroll
+        for (int c = 0; c < K1; ++c) acc[c][MT] = mfma_bf16(a[j], B16[c][j], acc[c][MT]);
+    }
+  } else {
+    f4 a[2][CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) a[0][j] = *reinterpret_cast<const f4*>(Lp.W + p * ldw + 16 * (kc + j) + 4 * q);
+#pragma unroll
+    for (int MT = 0; MT < NTO; ++MT) {
+      if (MT + 1 < NTO) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+          a[(MT + 1) & 1][j] = *reinterpret_cast<const f4*>(Lp.W + (16 * (MT + 1) + p) * ldw + 16 * (kc + j) + 4 * q);
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < K1; ++c) acc[c][MT] = mfma4(a[MT & 1][j][r], B[c][j][r], acc[c][MT]);
+    }
+  }
+}
 
 template <int K1>
 __device__ __forceinline__ void wide_input_jet(const FusedParams& P, int64_t ptc, int q, f4 (&b)[K1][1]) {
@@ -52,7 +113,7 @@ __device__ __forceinline__ void wide_input_jet(const FusedParams& P, int64_t ptc
 
 // out = act(W . in + b) for one layer.  FIRST: the input is (x, unit tangents) built from X.
 // LAST: no activation; outputs / loss / output adjoint instead of a stored jet.
-template <int NTI, int NTO, int K1, int ACT, bool FIRST, bool LAST, bool GRAD>
+template <int NTI, int NTO, int K1, int ACT, bool FIRST, bool LAST, bool GRAD, bool BF16>
 __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_fwd(const FusedParams P, const WideLayer Lp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -88,6 +149,13 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_fwd(const FusedParams 
     const int64_t ptc = valid ? pt : P.N - 1;
     f4 acc[K1][NTO];
     init_bias<NTO, K1>(Lp.b, acc, q);
+    auto load_chunk = [&](int kc, f4 (&Bc)[K1][CH]) {
+#pragma unroll
+      for (int c = 0; c < K1; ++c)
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+          Bc[c][j] = *reinterpret_cast<const f4*>(Lp.in_act + ((t * K1 + c) * NTI + kc + j) * 256 + lane * 4);
+    };
     for (int kc = 0; kc < NTI; kc += CH) {
       f4 B[K1][CH];
       if constexpr (FIRST) {
@@ -96,25 +164,9 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_fwd(const FusedParams 
 #pragma unroll
         for (int c = 0; c < K1; ++c) B[c][0] = b0[c][0];
       } else {
-#pragma unroll
-        for (int c = 0; c < K1; ++c)
-#pragma unroll
-          for (int j = 0; j < CH; ++j)
-            B[c][j] = *reinterpret_cast<const f4*>(Lp.in_act + ((t * K1 + c) * NTI + kc + j) * 256 + lane * 4);
+        load_chunk(kc, B);
       }
-#pragma unroll
-      for (int MT = 0; MT < NTO; ++MT) {
-        f4 a[CH];
-#pragma unroll
-        for (int j = 0; j < CH; ++j)
-          a[j] = *reinterpret_cast<const f4*>(Lp.W + (16 * MT + p) * LDW + 16 * (kc + j) + 4 * q);
-#pragma unroll
-        for (int j = 0; j < CH; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < K1; ++c) acc[c][MT] = mfma4(a[j][r], B[c][j][r], acc[c][MT]);
-      }
+      wide_mac_chunk<CH, K1, NTO, BF16>(Lp, kc, LDW, p, q, B, acc);
     }
     if constexpr (!LAST) {
       activate<ACT, NTO, K1>(acc);
@@ -193,7 +245,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_fwd(const FusedParams 
 
 // zbar = adjoint through the activation (HIDDEN; written back over g_in), abar_in = W^T zbar (NEED_GIN).
 // NTK = tiles of the layer OUTPUT (the contraction axis here), NTO = tiles of the layer INPUT.
-template <int NTK, int NTO, int K1, int ACT, bool HIDDEN, bool NEED_GIN>
+template <int NTK, int NTO, int K1, int ACT, bool HIDDEN, bool NEED_GIN, bool BF16>
 __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_bwd(const FusedParams P, const WideLayer Lp) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = lane & 15, q = lane >> 4;
@@ -224,21 +276,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_bwd(const FusedParams 
           for (int j = 0; j < CH; ++j)
             *reinterpret_cast<f4*>(Lp.g_in + ((t * K1 + c) * NTK + kc + j) * 256 + lane * 4) = g[c][j];
       }
-      if constexpr (NEED_GIN) {
-#pragma unroll
-        for (int MT = 0; MT < NTO; ++MT) {
-          f4 a[CH];
-#pragma unroll
-          for (int j = 0; j < CH; ++j)
-            a[j] = *reinterpret_cast<const f4*>(Lp.W + (16 * MT + p) * LDW + 16 * (kc + j) + 4 * q);
-#pragma unroll
-          for (int j = 0; j < CH; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-              for (int c = 0; c < K1; ++c) acc[c][MT] = mfma4(a[j][r], g[c][j][r], acc[c][MT]);
-        }
-      }
+      if constexpr (NEED_GIN) wide_mac_chunk<CH, K1, NTO, BF16>(Lp, kc, LDW, p, q, g, acc);
     }
     if constexpr (NEED_GIN) {
 #pragma unroll
@@ -250,15 +288,20 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_bwd(const FusedParams 
   }
 }
 
-// Split-K weight gradient.  blockIdx.y = row block (MTB output tiles), blockIdx.x*waves = split.
+// Split-K weight gradient.  The NTM/MTB row blocks of dW are the WAVES of one workgroup walking
+// the SAME point tiles, so the input-jet tiles every row block needs are fetched from HBM once
+// and re-read from L1/L2 (as separate workgroups they landed on different XCDs and the kernel ran
+// at the HBM roof re-reading them).
 // NTM = output tiles of the layer, NTN = input tiles.  FIRST: the layer input is (x, tangents).
-template <int MTB, int NTM, int NTN, int K1, bool FIRST>
+template <int MTB, int NTM, int NTN, int K1, bool FIRST, bool BF16>
 __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_wgrad(const FusedParams P, const WideLayer Lp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = lane & 15, q = lane >> 4;
   float* tb = smem + wave * (WIDE_MAX_PADS * TB_FLOATS);
-  const int rb = blockIdx.y;
+  constexpr int RB = NTM / MTB;                       // row blocks: 4 (W = 256), 2 (W = 128) or 1 (output layer)
+  constexpr int GPW = WIDE_WAVES / RB;                // tile groups per workgroup
+  const int rb = wave % RB;
   f4 dw[MTB][NTN];
   float bs[MTB];
 #pragma unroll
@@ -267,41 +310,72 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_wgrad(const FusedParam
 #pragma unroll
     for (int NT = 0; NT < NTN; ++NT) dw[MT][NT] = f4{0.f, 0.f, 0.f, 0.f};
   }
-  const int gw = blockIdx.x * WIDE_WAVES + wave, nw = gridDim.x * WIDE_WAVES;
-  for (int64_t t = gw; t < Lp.n_tiles; t += nw) {
-    f4 b0[K1][1];
+  const int gw = blockIdx.x * GPW + wave / RB, nw = gridDim.x * GPW;
+  // raw (acc-layout) tiles of ONE quantity, fetched one step ahead of their use: with a single wave
+  // per SIMD the HBM/L2 latency of these loads is otherwise fully exposed before every transpose.
+  f4 rz[MTB], ra[NTN];
+  auto fetch = [&](int64_t t, int c) {
+#pragma unroll
+    for (int MT = 0; MT < MTB; ++MT)
+      rz[MT] = *reinterpret_cast<const f4*>(Lp.g_in + ((t * K1 + c) * NTM + rb * MTB + MT) * 256 + lane * 4);
     if constexpr (FIRST) {
       const int64_t pt = (Lp.tile0 + t) * 16 + p;
+      f4 b0[K1][1];
       wide_input_jet<K1>(P, pt < P.N ? pt : P.N - 1, q, b0);
+#pragma unroll
+      for (int cc = 0; cc < K1; ++cc) ra[0] = (cc == c) ? b0[cc][0] : ra[0];
+    } else {
+#pragma unroll
+      for (int NT = 0; NT < NTN; ++NT)
+        ra[NT] = *reinterpret_cast<const f4*>(Lp.in_act + ((t * K1 + c) * NTN + NT) * 256 + lane * 4);
     }
+  };
+  // (fp32 mode: the 256 MFMAs per quantity leave no registers for the look-ahead — measured 30 %
+  // slower with it — so there the loads are issued in place)
+  constexpr bool AHEAD = BF16;
+  if (AHEAD && gw < Lp.n_tiles) fetch(gw, 0);
+  for (int64_t t = gw; t < Lp.n_tiles; t += nw) {
 #pragma unroll
     for (int c = 0; c < K1; ++c) {
       f4 zt[MTB], at[NTN];
+      if (!AHEAD) fetch(t, c);
 #pragma unroll
-      for (int MT = 0; MT < MTB; ++MT)
-        transpose_write(tb + MT * TB_FLOATS,
-                        *reinterpret_cast<const f4*>(Lp.g_in + ((t * K1 + c) * NTM + rb * MTB + MT) * 256 + lane * 4), p, q);
+      for (int MT = 0; MT < MTB; ++MT) transpose_write(tb + MT * TB_FLOATS, rz[MT], p, q);
 #pragma unroll
-      for (int NT = 0; NT < NTN; ++NT) {
-        f4 av;
-        if constexpr (FIRST) av = b0[c][0];
-        else av = *reinterpret_cast<const f4*>(Lp.in_act + ((t * K1 + c) * NTN + NT) * 256 + lane * 4);
-        transpose_write(tb + (4 + NT) * TB_FLOATS, av, p, q);
+      for (int NT = 0; NT < NTN; ++NT) transpose_write(tb + (4 + NT) * TB_FLOATS, ra[NT], p, q);
+      // the raw registers are free again: start the next quantity's (or the next tile's) loads now
+      if (AHEAD) {
+        if (c + 1 < K1) fetch(t, c + 1);
+        else if (t + nw < Lp.n_tiles) fetch(t + nw, 0);
       }
+      // fp32: element s <-> point 4s + q (one k-step of 16x16x4 per s);
+      // bf16: element j <-> point 4q + j (the single k = 16 step of 16x16x16)
 #pragma unroll
-      for (int MT = 0; MT < MTB; ++MT) zt[MT] = transpose_read(tb + MT * TB_FLOATS, p, q);
+      for (int MT = 0; MT < MTB; ++MT) zt[MT] = transpose_read<BF16>(tb + MT * TB_FLOATS, p, q);
 #pragma unroll
-      for (int NT = 0; NT < NTN; ++NT) at[NT] = transpose_read(tb + (4 + NT) * TB_FLOATS, p, q);
+      for (int NT = 0; NT < NTN; ++NT) at[NT] = transpose_read<BF16>(tb + (4 + NT) * TB_FLOATS, p, q);
       if (c == 0) {
 #pragma unroll
         for (int MT = 0; MT < MTB; ++MT) bs[MT] += (zt[MT][0] + zt[MT][1]) + (zt[MT][2] + zt[MT][3]);
       }
+      if constexpr (BF16) {
+        bf16x4 z16[MTB], a16[NTN];
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+        for (int MT = 0; MT < MTB; ++MT) z16[MT] = to_bf16x4(zt[MT]);
+#pragma unroll
+        for (int NT = 0; NT < NTN; ++NT) a16[NT] = to_bf16x4(at[NT]);
 #pragma unroll
         for (int MT = 0; MT < MTB; ++MT)
 #pragma unroll
-          for (int NT = 0; NT < NTN; ++NT) dw[MT][NT] = mfma4(zt[MT][s], at[NT][s], dw[MT][NT]);
+          for (int NT = 0; NT < NTN; ++NT) dw[MT][NT] = mfma_bf16(z16[MT], a16[NT], dw[MT][NT]);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int MT = 0; MT < MTB; ++MT)
+#pragma unroll
+            for (int NT = 0; NT < NTN; ++NT) dw[MT][NT] = mfma4(zt[MT][s], at[NT][s], dw[MT][NT]);
+      }
     }
   }
   // one flush per wave into the flat torch-layout gradient (out_d x in_d row-major)
@@ -327,13 +401,13 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_wgrad(const FusedParam
 
 // launchers, one translation unit per padded width (pinn_wide_w128.hip / _w256.hip)
 template <int NTW>
-int launch_wide_fwd(int which /*0 first, 1 hidden, 2 last*/, int K1, int act, bool grad, const FusedParams& P,
+int launch_wide_fwd(int which /*0 first, 1 hidden, 2 last*/, int K1, int prec, bool grad, const FusedParams& P,
                     const WideLayer& Lp, int grid, hipStream_t s);
 template <int NTW>
-int launch_wide_bwd(int which /*0 first, 1 hidden, 2 last*/, int K1, int act, const FusedParams& P, const WideLayer& Lp,
+int launch_wide_bwd(int which /*0 first, 1 hidden, 2 last*/, int K1, int prec, const FusedParams& P, const WideLayer& Lp,
                     int grid, hipStream_t s);
 template <int NTW>
-int launch_wide_wgrad(int which /*0 first, 1 hidden, 2 last*/, int K1, const FusedParams& P, const WideLayer& Lp,
+int launch_wide_wgrad(int which /*0 first, 1 hidden, 2 last*/, int K1, int prec, const FusedParams& P, const WideLayer& Lp,
                       int grid_x, hipStream_t s);
 
 }  // namespace pinn

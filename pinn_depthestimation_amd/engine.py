@@ -38,6 +38,7 @@ class NetDesc:
     grad_cols: Tuple[int, ...] = ()      # X columns whose inputs have requires_grad "true" (train.py:87)
     activation: int = ACT_TANH
     engine: int = ENGINE_AUTO
+    precision: int = 0                   # _lib.PREC_F32 / PREC_BF16 (bf16 MFMA operands, wide engine only)
 
     @property
     def k(self) -> int:
@@ -54,7 +55,8 @@ class NetDesc:
 
     def with_(self, **kw) -> "NetDesc":
         d = dict(d_in=self.d_in, d_out=self.d_out, n_hidden=self.n_hidden, width=self.width,
-                 grad_cols=self.grad_cols, activation=self.activation, engine=self.engine)
+                 grad_cols=self.grad_cols, activation=self.activation, engine=self.engine,
+                 precision=self.precision)
         d.update(kw)
         return NetDesc(**d)
 
@@ -66,7 +68,7 @@ class NetDesc:
         d.k = self.k
         for j in range(_lib.PINN_MAX_DIRS):
             d.dir_col[j] = self.grad_cols[j] if j < self.k else -1
-        d.activation, d.engine = self.activation, self.engine
+        d.activation, d.engine, d.precision = self.activation, self.engine, self.precision
         return d
 
     @staticmethod

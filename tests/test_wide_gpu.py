@@ -91,3 +91,29 @@ def test_wide_chunked_12x256_matches_generic():
     sg = Engine(desc.with_(engine=ENGINE_GENERIC)).residual_loss_grad(spec, scale, params, X, gg)
     assert torch.allclose(sw, sg, rtol=3e-5)
     assert rel_l2(gw.cpu(), gg.cpu()) < 3e-5
+
+
+def test_wide_bf16_mfma_mode():
+    """PINN_PREC_BF16 (BASELINE configs[3]: bf16 MFMA, fp32 accumulate / residual): hidden-layer
+    GEMM operands are rounded to bf16 (8-bit mantissa), so the tolerance is 2e-2 on the loss and
+    5e-2 (relative L2) on the gradient against the fp64 oracle; the fp32 mode of the same engine
+    is the bit-for-bit-class reference (3e-6 / 3e-5 above)."""
+    from pinn_depthestimation_amd._lib import PREC_BF16
+    N = 2000
+    params, X, desc, res, inn, outn = make("ns_2x256", N)
+    spec = ResidualSpec.from_names(res, inn, desc.grad_cols, outn)
+    flat, Xd = O.flatten(params).cuda(), X.cuda().contiguous()
+    l64, g64 = oracle_loss_and_grad(params, X, res, inn, outn, desc.grad_cols, torch.float64)
+    eng = Engine(desc.with_(precision=PREC_BF16))
+    scale = torch.full((3,), 1.0 / N, device="cuda")
+    grad = torch.zeros(desc.n_params, device="cuda")
+    sums = eng.residual_loss_grad(spec, scale, flat, Xd, grad)
+    loss = float((sums * scale).sum())
+    el, eg = abs(loss - float(l64)) / float(l64), rel_l2(grad.cpu(), g64)
+    print(f"bf16 mode: loss rel err {el:.2e}, grad rel-L2 err {eg:.2e}")
+    assert el < 2e-2 and eg < 5e-2
+    assert el > 1e-6            # it really is the reduced-precision path
+    # narrow networks have no bf16 path: loud refusal, no silent fp32
+    from pinn_depthestimation_amd import PinnError
+    with pytest.raises(PinnError, match="bf16"):
+        Engine(NetDesc(3, 4, 8, 64, (0, 1, 2), precision=PREC_BF16)).forward(torch.zeros(29636, device="cuda"), Xd)
