@@ -14,13 +14,14 @@
 // r = 0..3 contiguous: one 16-byte load from the row-major (padded) weights.  The
 // reverse sweep uses the same chain on W^T.  Only the weight-gradient GEMM
 // (dW = Zbar . A^T, contraction over points) needs points on the K axis: each
-// 16x16 block is transposed through a wave-private 1.25 KB LDS pad.
+// 16x16 block is transposed through a wave-private, XOR-swizzled 1 KB LDS pad.
 //
 // Activations needed by the reverse sweep are spilled to a per-wave global scratch
 // slot in fragment-native order (fully coalesced 16 B/lane both ways; written once,
-// read twice, L2/MALL resident).  dW/db are accumulated with LDS float atomics in a
-// per-workgroup copy of the (padded) gradient, written out once per workgroup and
-// summed across workgroups by a second kernel in a fixed order.
+// read once).  dW/db are accumulated in a per-workgroup LDS copy of the (padded)
+// gradient with plain vector read-modify-write under a per-layer wave-level lock
+// (LDS fp32 atomics are ~150 cycles per wave-instruction on gfx950), written out once
+// per workgroup and summed across workgroups by a second kernel in a fixed order.
 #pragma once
 #include <string.h>
 #include <type_traits>
@@ -187,18 +188,6 @@ __device__ __forceinline__ void unspill(const float* __restrict__ slot, f4 (&v)[
   for (int c = 0; c < K1; ++c)
 #pragma unroll
     for (int MT = 0; MT < NT; ++MT) v[c][MT] = *reinterpret_cast<const f4*>(slot + (c * NT + MT) * 256 + lane * 4);
-}
-
-// sum over the 16 lanes of a DPP row (= the 16 points of a tile); result valid in lane 15 of each row
-__device__ __forceinline__ float row_sum16(float v) {
-#define PINN_DPP_ADD(ctrl)                                                                              \
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
-  PINN_DPP_ADD(0x111);  // row_shr:1
-  PINN_DPP_ADD(0x112);  // row_shr:2
-  PINN_DPP_ADD(0x114);  // row_shr:4
-  PINN_DPP_ADD(0x118);  // row_shr:8
-#undef PINN_DPP_ADD
-  return v;
 }
 
 // acc-layout 16x16 block (features x points) -> operand layout of the weight-gradient GEMM:
