@@ -68,17 +68,27 @@ def Navier_Stokes(t, x, y, h, z, u, v):
     return _mean_sq(mass, mom_x, mom_y)
 
 
-def physics_equation(x, y, h, U, V, eta_mean, Hrms, k):
+def physics_equation(x, y, h, U, V, eta_mean, Hrms, k, corrected=False):
     """physics.py:91-120 — steady wave-averaged continuity + momentum with quadratic bottom
-    friction.  Bug-compatible: the reference's E = 1/8**rho*g*Hrms**2 (physics.py:106) is
-    exactly 0.0, so the radiation-stress gradients vanish and Hrms, k do not enter."""
-    fused = fused_residual("physics_equation", (x, y), (h, U, V, eta_mean, Hrms, k))
-    if fused is not None:
-        return fused
+    friction.  Default is bug-compatible: the reference's E = 1/8**rho*g*Hrms**2 (physics.py:106)
+    is exactly 0.0, so the radiation-stress gradients vanish and Hrms, k do not enter.
+
+    corrected=True (an extension, not reference behaviour) evaluates what the line evidently
+    meant, E = 1/8 * rho * g * Hrms**2, with Sxx = E (2kh/sinh(2kh) + 1/2), Syy = E kh/sinh(2kh)
+    (physics.py:107-109); it runs on the generic compute_gradient path (HIP jet + autograd)."""
+    if not corrected:
+        fused = fused_residual("physics_equation", (x, y), (h, U, V, eta_mean, Hrms, k))
+        if fused is not None:
+            return fused
     d = compute_gradient
     g, rho, cd = 9.81, 1025, 0.002
     inv_depth = 1 / (rho * (eta_mean + h))
     mass = d(U, x) + d(V, y)
     mom_x = U * d(U, x) + V * d(U, y) + g * d(eta_mean, x) + inv_depth * (rho * cd * U * abs(U))
     mom_y = U * d(V, x) + V * d(V, y) + g * d(eta_mean, y) + inv_depth * (rho * cd * V * abs(V))
+    if corrected:
+        E = (1.0 / 8.0) * rho * g * Hrms ** 2
+        ratio = k * h / torch.sinh(2 * k * h)
+        mom_x = mom_x + inv_depth * d(E * (2 * ratio + 0.5), x)
+        mom_y = mom_y + inv_depth * d(E * ratio, y)
     return _mean_sq(mass, mom_x, mom_y)

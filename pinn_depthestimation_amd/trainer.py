@@ -167,8 +167,12 @@ class PINN:
         self.iter += 1                                                                        # train.py:160
         if self.iter % self.log_every == 0 or self.iter % 1000 == 0:
             self._log(fidelity_loss.item(), residual_loss.item(), loss.item())
-        if self.checkpoint_every and self.iter % self.checkpoint_every == 0:
-            self.save_checkpoint(f"model_{self.iter}.pth")                                    # train.py:175-179
+        if self.checkpoint_every:
+            every = self.checkpoint_every
+            if self.config.variant == "newmethod" and self.checkpoint_every == 1000:
+                every = 10000 if self.iter <= 45000 else 1000                                 # train_newmethod.py:181-188
+            if self.iter % every == 0:
+                self.save_checkpoint(f"model_{self.iter}.pth")                                # train.py:175-179
         return loss
 
     def _log(self, fid: float, res: float, tot: float):

@@ -111,3 +111,46 @@ def test_minibatch_resampled_collocation_is_seeded_and_descends():
     # agree to rounding (observed ~1e-8), not bit for bit
     assert np.allclose(runs[0], runs[1], rtol=1e-5, atol=0)
     assert runs[0][-5:].mean() < 0.05 * runs[0][:5].mean()       # and it trains
+
+
+def test_corrected_radiation_stress_switch():
+    """corrected=True is an extension: E = 1/8*rho*g*Hrms^2 instead of the reference's
+    exact zero.  Checked against the same formulas under fp64 autograd; Hrms and k now get gradient."""
+    import dnn
+    import physics
+    z = load("g4_pe_8x64_conditioned.npz")
+    sd = state_dict(z)
+    with torch.no_grad():
+        sd["layers.layer_8.bias"][4] = 0.2     # Hrms ~ 0.2 m
+        sd["layers.layer_8.bias"][5] = 1.0     # k ~ 1 rad/m  (2kh ~ 1.5: sinh well conditioned)
+    model = dnn.DNN(layers_of(sd), 0.0, "xavier")
+    model.load_state_dict(sd)
+    model.to("cuda")
+    X = z["X"]
+    c = [torch.tensor(X[:, i:i + 1].astype(np.float64), requires_grad=True).float().cuda() for i in range(2)]
+    pred = model(torch.cat(c, dim=-1))
+    cols = [pred[:, i:i + 1] for i in range(6)]
+    loss = physics.physics_equation(c[0], c[1], *cols, corrected=True)
+    model.zero_grad()
+    loss.backward()
+    got = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu()
+    # fp64 autograd restatement of the corrected formulas
+    p64 = [q.double().requires_grad_(True) for q in O.params_from_state_dict(sd)]
+    xc = O.split_columns(torch.from_numpy(X).double(), (0, 1))
+    Y = O.mlp_forward(p64, torch.cat(xc, -1))
+    h, U, V, eta, Hrms, k = [Y[:, i:i + 1] for i in range(6)]
+    d = O.compute_gradient
+    g_, rho, cd = 9.81, 1025, 0.002
+    inv = 1 / (rho * (eta + h))
+    E = 0.125 * rho * g_ * Hrms ** 2
+    ratio = k * h / torch.sinh(2 * k * h)
+    fc = d(U, xc[0]) + d(V, xc[1])
+    fx = U * d(U, xc[0]) + V * d(U, xc[1]) + g_ * d(eta, xc[0]) + inv * (rho * cd * U * abs(U)) + inv * d(E * (2 * ratio + 0.5), xc[0])
+    fy = U * d(V, xc[0]) + V * d(V, xc[1]) + g_ * d(eta, xc[1]) + inv * (rho * cd * V * abs(V)) + inv * d(E * ratio, xc[1])
+    ref = (fc ** 2).mean() + (fx ** 2).mean() + (fy ** 2).mean()
+    gref = O.flat_grad(ref, p64)
+    assert abs(loss.item() - float(ref)) / float(ref) < 1e-4
+    assert rel_l2(got, gref) < 1e-3
+    W = layers_of(sd)[-2]
+    last_w = got[got.numel() - 6 * W - 6: got.numel() - 6].reshape(6, W)
+    assert torch.count_nonzero(last_w[4:6]) > 0          # Hrms, k participate now
