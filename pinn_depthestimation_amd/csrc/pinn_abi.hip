@@ -155,8 +155,7 @@ static int32_t forward_impl(const pinn_desc* desc, const float* params, const fl
   if (N == 0) return PINN_OK;
   if (!jet) { n.k = 0; n.K1 = 1; dY = nullptr; }
   if (jet && n.k == 0) { set_error("forward_jet needs k >= 1"); return PINN_ERR_INVALID; }
-  int e = pick_engine(desc, n, &rc); if (rc) return rc;
-  if (e == PINN_ENGINE_WIDE && desc->engine == PINN_ENGINE_AUTO && !wide_supports(n)) e = PINN_ENGINE_GENERIC;
+  const int e = pick_engine(desc, n, &rc); if (rc) return rc;
   return e == PINN_ENGINE_FUSED ? fused_forward(n, params, X, N, Y, dY, ws, ws_bytes, (hipStream_t)stream)
        : e == PINN_ENGINE_WIDE ? wide_forward(n, params, X, N, Y, dY, ws, ws_bytes, (hipStream_t)stream)
                                : generic_forward(n, params, X, N, Y, dY, ws, ws_bytes, (hipStream_t)stream);

@@ -159,12 +159,7 @@ def test_leaky_relu_kaiming_network(engine):
 
 
 def test_adam_step_matches_torch():
-    P = 1000
     g = torch.Generator().manual_seed(11)
-    p0 = torch.randn(P, generator=g)
-    ref = p0.clone().requires_grad_(True)
-    opt = torch.optim.Adam([ref], lr=1e-4)
-    sch = torch.optim.lr_scheduler.StepLR(opt, step_size=3, gamma=0.8)
     eng = Engine(NetDesc(2, 3, 2, 4, (0,)))
     P = eng.n_params
     p0 = torch.randn(P, generator=g)
