@@ -154,3 +154,46 @@ def test_corrected_radiation_stress_switch():
     W = layers_of(sd)[-2]
     last_w = got[got.numel() - 6 * W - 6: got.numel() - 6].reshape(6, W)
     assert torch.count_nonzero(last_w[4:6]) > 0          # Hrms, k participate now
+
+
+def _shape_cfg(d_in, hidden, width, d_out, inputs, grad, outputs, variant="train"):
+    rg = lambda k: {"requires_grad": ["true" if k in grad else "false"]}
+    cfg = {"layers": {"input_features": d_in, "hidden_layers": hidden, "hidden_width": width, "output_features": d_out},
+           "adam_optimizer": {"max_it": 3, "learning_rate": 1e-4, "scheduler_step_size": 10000, "scheduler_gamma": 0.8},
+           "lbfgs_optimizer": {"max_it": 3.0, "learning_rate": 1, "max_evaluation": 6.0, "history_size": 100,
+                               "tolerance_grad": 1e-5, "tolerance_change": 1e-7, "line_search_fn": "strong_wolfe"},
+           "loss": {"weight_fid_loss": 1, "weight_res_loss": 1}}
+    if variant == "newmethod":
+        cfg["data"] = {"inputs": {k: rg(k) for k in inputs}, "trues": outputs[:-1], "unknowns": outputs[-1:]}
+    else:
+        cfg["data_fidelity"] = {"inputs": list(inputs), "outputs": list(outputs)}
+        cfg["data_residual"] = {"inputs": {k: rg(k) for k in inputs}, "outputs": {k: {"file": k} for k in outputs}}
+    return cfg
+
+
+@pytest.mark.parametrize("name,cfg", [
+    ("config_CMB.json", _shape_cfg(2, 10, 10, 6, "xy", "xy", ["h", "U", "V", "eta_mean", "Hrms", "k"])),
+    ("config_CMB_h.json", _shape_cfg(2, 100, 20, 3, "xy", "xy", ["U", "V", "h"], "newmethod")),
+    ("config.json", _shape_cfg(5, 100, 20, 4, "txyuv", "txy", ["h", "z", "u", "v"])),
+    ("config_txyz.json", _shape_cfg(4, 20, 20, 4, "txyz", "txy", ["h", "z", "u", "v"])),
+])
+def test_every_reference_config_shape_trains(name, cfg):
+    """The four network/variable layouts the reference's JSON files describe (train.py:52-56,86-88),
+    on synthetic data: Adam steps then one LBFGS.step run end to end and the loss stays finite and drops."""
+    from pinn_depthestimation_amd.trainer import pinn
+    torch.manual_seed(3)
+    g = np.random.RandomState(3)
+    d_in, d_out = cfg["layers"]["input_features"], cfg["layers"]["output_features"]
+    nf = d_out - 1 if "data" in cfg else d_out
+    Xr = g.uniform(-1, 1, (500, d_in)).astype(np.float32)
+    Xf = Xr if "data" in cfg else g.uniform(-1, 1, (40, d_in)).astype(np.float32)
+    Tf = g.uniform(0.2, 0.8, (Xf.shape[0], nf)).astype(np.float32)
+    tr = pinn(Xf, Tf, Xr, cfg, log_every=1, checkpoint_every=0)
+    if tr.spec.name == "physics_equation":
+        with torch.no_grad():                      # keep eta_mean + h away from 0 (SURVEY §7)
+            tr.dnn.layers[-1].bias[0] = 0.75
+            tr.dnn.layers[-1].bias[3] = 0.0
+    tr.train()
+    losses = np.array([h[3] for h in tr.history])
+    assert len(losses) >= 4 and np.all(np.isfinite(losses)), (name, losses)
+    assert losses[-1] < losses[0], (name, losses)
