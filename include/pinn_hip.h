@@ -16,6 +16,7 @@
  *                           continuity_ftemp, Navier_Stokes, physics_equation)
  *                           fused with loss.backward() (train.py:154,191)
  *   pinn_mse_loss_grad      train.py:131-141 (weighted fidelity MSE) + backward
+ *   pinn_residual_mse_loss_grad  train_newmethod.py:122-159 (both on one forward) + backward
  *   pinn_adam_step          torch.optim.Adam.step as called at train.py:192
  *
  * Conventions
@@ -145,6 +146,16 @@ int32_t pinn_mse_loss_grad(const pinn_desc* desc, const float* params, const flo
                            const float* T, int64_t N, int32_t n_cols, const int32_t* out_col,
                            const float* col_scale, float* col_sums, float* grad_flat,
                            void* ws, int64_t ws_bytes, void* stream);
+
+/* residual + fidelity on ONE point set in one pass (train_newmethod.py:122-159: a single forward
+ * feeds both F.mse_loss on the `trues` columns and the residual):
+ * grad_flat += sum_t term_scale[t] d term_sums[t]/d theta + sum_j col_scale[j] d col_sums[j]/d theta */
+int32_t pinn_residual_mse_loss_grad(const pinn_desc* desc, const pinn_residual_spec* spec,
+                                    const float* term_scale, const float* T, int32_t n_cols,
+                                    const int32_t* out_col, const float* col_scale,
+                                    const float* params, const float* X, int64_t N,
+                                    float* term_sums, float* col_sums, float* grad_flat,
+                                    void* ws, int64_t ws_bytes, void* stream);
 
 /* torch.optim.Adam single-tensor update on flat buffers (amsgrad off, weight_decay 0,
  * maximize off): m,v are exp_avg / exp_avg_sq; step is the 1-based step count;

@@ -30,14 +30,16 @@ int make_net(const pinn_desc* d, Net* n);  // validates, returns PINN_OK or erro
 
 // what a loss call asks the engines for
 struct LossReq {
-  int kind;  // 0 = residual, 1 = mse
+  int kind;  // 0 = residual, 1 = mse, 2 = residual + mse on the same points (one pass)
   pinn_residual_spec spec;
+  const float* scale;   // residual: device term_scale (may be null when !want_grad)
+  float* sums;          // residual: device term_sums
+  int n_terms;          // residual: number of terms
   // mse
   const float* T; int n_cols; int out_col[PINN_MAX_ROLES];
-  const float* scale;   // device: term_scale / col_scale (may be null when !want_grad)
-  float* sums;          // device: term_sums / col_sums
+  const float* mse_scale;   // device col_scale
+  float* mse_sums;          // device col_sums
   float* grad;          // device flat grad (+=) or null
-  int n_terms;
 };
 
 // generic engine (pinn_generic.hip)

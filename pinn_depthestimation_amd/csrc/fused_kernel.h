@@ -39,7 +39,8 @@ constexpr int FUSED_WAVES = PINN_FUSED_WAVES;
 constexpr int FUSED_THREADS = FUSED_WAVES * 64;
 constexpr int TB_FLOATS = 256;                // one 16x16 fp32 block, XOR-swizzled (see transpose_write)
 constexpr int TB_PER_WAVE = 8;                // 4 pads for the Zbar tiles + 4 for the A tiles of one quantity
-constexpr int MAX_SUMS = 8;
+constexpr int MAX_SUMS = 12;               // residual terms at [0,4), fidelity columns at [4,12)
+constexpr int MSE_SUM0 = 4;
 
 struct FusedParams {
   int d_in, d_out, L, act;
@@ -52,14 +53,16 @@ struct FusedParams {
   float* scratch;     // activation spill, scratch_per_wave floats per wave
   int64_t scratch_per_wave;
   float* Y; float* dY;  // forward outputs (may be null)
-  int loss_kind;        // 0 none, 1 residual, 2 mse
+  int loss_kind;        // bit 0: PDE residual, bit 1: fidelity MSE (both: one pass, train_newmethod.py:122-159)
   int residual_id;
-  int out_col[PINN_MAX_ROLES];
+  int out_col[PINN_MAX_ROLES];   // residual: output column of each role
   int q_of[PINN_MAX_DIRS];   // engine quantity (1 + direction index) of each residual direction role
-  int n_cols;                // mse
-  const float* T;
   float thr, anchor; int xcol;
-  const float* scale;        // device term scales (null when no gradient wanted)
+  const float* scale;        // residual: device term scales (null when no gradient wanted)
+  int n_cols;                // mse: number of target columns
+  int mse_col[PINN_MAX_ROLES];   // mse: output column of each target column
+  const float* T;            // mse: targets (N, n_cols)
+  const float* mse_scale;    // mse: device column scales
   float* wg_sums;            // [grid][MAX_SUMS]
   float* wg_grads;           // acc_lds: [grid][PP]; else [nrep][PP] (atomics)
   int acc_lds, nrep;
@@ -348,7 +351,7 @@ struct ScatterMap {
 
 // roles' adjoints g[c][r] (identical in all four lane groups) -> adjoint tile G in acc layout,
 // through the wave-private LDS pad (idle at this point): row (c*NR + r) holds the 16 points.
-template <int K1, int NC, int NR>
+template <int K1, int NC, int NR, bool ACCUM = false>
 __device__ __forceinline__ void scatter_adjoint(float* __restrict__ tb, const float (&g)[NC][NR],
                                                 const ScatterMap<K1>& sm, f4 (&G)[K1][1], bool valid, int p, int q) {
   if (q == 0) {
@@ -365,7 +368,7 @@ __device__ __forceinline__ void scatter_adjoint(float* __restrict__ tb, const fl
       const int ci = sm.cinv[ce], ro = sm.role_of[r2];
       const bool ok = valid && ci >= 0 && ci < NC && ro >= 0;
       const float val = tb[ok ? (ci * NR + ro) * 16 + p : p];
-      G[ce][0][r2] = ok ? val : 0.f;
+      G[ce][0][r2] = (ACCUM ? G[ce][0][r2] : 0.f) + (ok ? val : 0.f);
     }
   __builtin_amdgcn_wave_barrier();
 }
@@ -394,6 +397,78 @@ __device__ __forceinline__ void residual_tile(const FusedParams& P, const f4 (&o
     for (int t = 0; t < NT; ++t) sums[t] += sq[t];
   }
   if constexpr (GRAD) scatter_adjoint<K1, 1 + ND, NR>(tb, g, sm, G, valid, p, q);
+}
+
+template <int K1>
+__device__ __forceinline__ void build_scatter_maps(const FusedParams& P, int q, ScatterMap<K1>& sm, ScatterMap<K1>& sm_mse) {
+#pragma unroll
+  for (int r2 = 0; r2 < 4; ++r2) {
+    int ro = -1, rm = -1;
+    for (int r = PINN_MAX_ROLES - 1; r >= 0; --r) {
+      ro = (P.out_col[r] == 4 * q + r2) ? r : ro;
+      rm = (r < P.n_cols && P.mse_col[r] == 4 * q + r2) ? r : rm;
+    }
+    sm.role_of[r2] = ro;
+    sm_mse.role_of[r2] = rm;
+  }
+  sm.cinv[0] = 0; sm_mse.cinv[0] = 0;
+#pragma unroll
+  for (int ce = 1; ce < K1; ++ce) {
+    int ci = -1;
+    for (int d = PINN_MAX_DIRS - 1; d >= 0; --d) ci = (P.q_of[d] == ce) ? 1 + d : ci;
+    sm.cinv[ce] = ci;
+    sm_mse.cinv[ce] = -1;
+  }
+}
+
+// Everything that happens on the output tile of one 16-point tile: optional Y/dY stores, PDE
+// residual and/or fidelity MSE (train.py:131-157), loss partial sums, output adjoint G.
+template <int K1, bool GRAD>
+__device__ __forceinline__ void loss_epilogue(const FusedParams& P, const f4 (&out)[K1][1], f4 (&G)[K1][1],
+                                              float (&sums)[MAX_SUMS], const ScatterMap<K1>& sm,
+                                              const ScatterMap<K1>& sm_mse, float* __restrict__ tb, int64_t pt,
+                                              int64_t ptc, bool valid, int p, int q) {
+  if (P.Y != nullptr && valid) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = 4 * q + r;
+      if (o < P.d_out) {
+        P.Y[pt * P.d_out + o] = out[0][0][r];
+        if (P.dY != nullptr) {
+#pragma unroll
+          for (int c = 1; c < K1; ++c) P.dY[((int64_t)(c - 1) * P.N + pt) * P.d_out + o] = out[c][0][r];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < K1; ++c) G[c][0] = f4{0.f, 0.f, 0.f, 0.f};
+  if (P.loss_kind & 1) {
+    if (P.residual_id == PINN_RES_NAVIER_STOKES) {
+      if constexpr (K1 >= 4) residual_tile<ResNavierStokes, K1, GRAD>(P, out, G, sums, sm, tb, valid, false, p, q);
+    } else if (P.residual_id == PINN_RES_PHYSICS_EQUATION) {
+      if constexpr (K1 >= 3) residual_tile<ResPhysicsEquation, K1, GRAD>(P, out, G, sums, sm, tb, valid, false, p, q);
+    } else {
+      if constexpr (K1 >= 3) {
+        const bool masked = P.residual_id == PINN_RES_CONTINUITY_ONLY && P.X[ptc * P.d_in + P.xcol] < P.thr;
+        residual_tile<ResContinuity, K1, GRAD>(P, out, G, sums, sm, tb, valid, masked, p, q);
+      }
+    }
+  }
+  if (P.loss_kind & 2) {
+    float gm[1][PINN_MAX_ROLES];
+#pragma unroll
+    for (int j = 0; j < PINN_MAX_ROLES; ++j) {
+      gm[0][j] = 0.f;
+      if (j < P.n_cols) {
+        const float y = gather_out(out[0][0], P.mse_col[j], p);
+        const float d = P.T[ptc * P.n_cols + j] - y;                  // train.py:141 (true - pred)
+        if (valid && q == 0) sums[MSE_SUM0 + j] += d * d;
+        if (GRAD) gm[0][j] = -2.f * P.mse_scale[j] * d;
+      }
+    }
+    if constexpr (GRAD) scatter_adjoint<K1, 1, PINN_MAX_ROLES, true>(tb, gm, sm_mse, G, valid, p, q);
+  }
 }
 
 // Diagnostic build only (-DPINN_DIAG): s_memtime stamps per phase, printed by wave 0 of block 0.
@@ -435,23 +510,8 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
 #pragma unroll
   for (int j = 0; j < MAX_SUMS; ++j) sums[j] = 0.f;
 
-  ScatterMap<K1> sm;
-  {
-    const int n_roles = P.loss_kind == 2 ? P.n_cols : PINN_MAX_ROLES;
-#pragma unroll
-    for (int r2 = 0; r2 < 4; ++r2) {
-      int ro = -1;
-      for (int r = PINN_MAX_ROLES - 1; r >= 0; --r) ro = (r < n_roles && P.out_col[r] == 4 * q + r2) ? r : ro;
-      sm.role_of[r2] = ro;
-    }
-    sm.cinv[0] = 0;
-#pragma unroll
-    for (int ce = 1; ce < K1; ++ce) {
-      int ci = -1;
-      for (int d = PINN_MAX_DIRS - 1; d >= 0; --d) ci = (P.q_of[d] == ce) ? 1 + d : ci;
-      sm.cinv[ce] = ci;
-    }
-  }
+  ScatterMap<K1> sm, sm_mse;
+  build_scatter_maps<K1>(P, q, sm, sm_mse);
   const int gw = blockIdx.x * FUSED_WAVES + wave, nw = gridDim.x * FUSED_WAVES;
   float* scr = P.scratch + (int64_t)gw * P.scratch_per_wave;
   constexpr int SLOT = K1 * NTH * 256;  // floats per spilled layer
@@ -518,47 +578,8 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
     }
 
     // ---- outputs / loss -----------------------------------------------------------------------
-    if (P.Y != nullptr && valid) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int o = 4 * q + r;
-        if (o < P.d_out) {
-          P.Y[pt * P.d_out + o] = out[0][0][r];
-          if (P.dY != nullptr) {
-#pragma unroll
-            for (int c = 1; c < K1; ++c) P.dY[((int64_t)(c - 1) * P.N + pt) * P.d_out + o] = out[c][0][r];
-          }
-        }
-      }
-    }
     f4 G[K1][1];
-#pragma unroll
-    for (int c = 0; c < K1; ++c) G[c][0] = f4{0.f, 0.f, 0.f, 0.f};
-    if (P.loss_kind == 1) {
-      if (P.residual_id == PINN_RES_NAVIER_STOKES) {
-        if constexpr (K1 >= 4) residual_tile<ResNavierStokes, K1, GRAD>(P, out, G, sums, sm, tb, valid, false, p, q);
-      } else if (P.residual_id == PINN_RES_PHYSICS_EQUATION) {
-        if constexpr (K1 >= 3) residual_tile<ResPhysicsEquation, K1, GRAD>(P, out, G, sums, sm, tb, valid, false, p, q);
-      } else {
-        if constexpr (K1 >= 3) {
-          const bool masked = P.residual_id == PINN_RES_CONTINUITY_ONLY && P.X[ptc * P.d_in + P.xcol] < P.thr;
-          residual_tile<ResContinuity, K1, GRAD>(P, out, G, sums, sm, tb, valid, masked, p, q);
-        }
-      }
-    } else if (P.loss_kind == 2) {
-      float gm[1][PINN_MAX_ROLES];
-#pragma unroll
-      for (int j = 0; j < PINN_MAX_ROLES; ++j) {
-        gm[0][j] = 0.f;
-        if (j < P.n_cols) {
-          const float y = gather_out(out[0][0], P.out_col[j], p);
-          const float d = P.T[ptc * P.n_cols + j] - y;                  // train.py:141 (true - pred)
-          if (valid && q == 0) sums[j] += d * d;
-          if (GRAD) gm[0][j] = -2.f * P.scale[j] * d;
-        }
-      }
-      if constexpr (GRAD) scatter_adjoint<K1, 1, PINN_MAX_ROLES>(tb, gm, sm, G, valid, p, q);
-    }
+    loss_epilogue<K1, GRAD>(P, out, G, sums, sm, sm_mse, tb, pt, ptc, valid, p, q);
 
     PINN_STAMP(2);
     // ---- reverse sweep ------------------------------------------------------------------------

@@ -219,14 +219,42 @@ int32_t pinn_mse_loss_grad(const pinn_desc* desc, const float* params, const flo
   }
   if (n_cols < 1 || n_cols > PINN_MAX_ROLES) { set_error("n_cols=%d outside 1..%d", n_cols, PINN_MAX_ROLES); return PINN_ERR_INVALID; }
   LossReq rq; memset(&rq, 0, sizeof(rq));
-  rq.kind = 1; rq.T = T; rq.n_cols = n_cols; rq.scale = col_scale; rq.sums = col_sums; rq.grad = grad_flat;
-  rq.n_terms = n_cols;
+  rq.kind = 1; rq.T = T; rq.n_cols = n_cols; rq.mse_scale = col_scale; rq.mse_sums = col_sums; rq.grad = grad_flat;
   for (int j = 0; j < n_cols; ++j) {
     if (out_col[j] < 0 || out_col[j] >= n.d_out) { set_error("out_col[%d]=%d out of range", j, out_col[j]); return PINN_ERR_INVALID; }
     rq.out_col[j] = out_col[j];
   }
   if (N == 0) { (void)hipMemsetAsync(col_sums, 0, n_cols * sizeof(float), (hipStream_t)stream); return PINN_OK; }
   n.k = 0; n.K1 = 1;  // the fidelity term needs no input derivatives
+  const int e = pick_engine(desc, n, &rc); if (rc) return rc;
+  return e == PINN_ENGINE_FUSED ? fused_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream)
+       : e == PINN_ENGINE_WIDE ? wide_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream)
+                               : generic_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int32_t pinn_residual_mse_loss_grad(const pinn_desc* desc, const pinn_residual_spec* spec, const float* term_scale,
+                                    const float* T, int32_t n_cols, const int32_t* out_col, const float* col_scale,
+                                    const float* params, const float* X, int64_t N, float* term_sums,
+                                    float* col_sums, float* grad_flat, void* ws, int64_t ws_bytes, void* stream) {
+  Net n; int rc = make_net(desc, &n); if (rc) return rc;
+  rc = check_spec(n, spec); if (rc) return rc;
+  if (!params || ((!X || !T) && N > 0) || N < 0 || !term_sums || !col_sums || !out_col || !grad_flat || !term_scale ||
+      !col_scale) {
+    set_error("NULL pointer argument"); return PINN_ERR_INVALID;
+  }
+  if (n_cols < 1 || n_cols > PINN_MAX_ROLES) { set_error("n_cols=%d outside 1..%d", n_cols, PINN_MAX_ROLES); return PINN_ERR_INVALID; }
+  LossReq rq; memset(&rq, 0, sizeof(rq));
+  rq.kind = 2; rq.spec = *spec; rq.scale = term_scale; rq.sums = term_sums; rq.n_terms = residual_terms(spec->residual_id);
+  rq.T = T; rq.n_cols = n_cols; rq.mse_scale = col_scale; rq.mse_sums = col_sums; rq.grad = grad_flat;
+  for (int j = 0; j < n_cols; ++j) {
+    if (out_col[j] < 0 || out_col[j] >= n.d_out) { set_error("out_col[%d]=%d out of range", j, out_col[j]); return PINN_ERR_INVALID; }
+    rq.out_col[j] = out_col[j];
+  }
+  if (N == 0) {
+    (void)hipMemsetAsync(term_sums, 0, rq.n_terms * sizeof(float), (hipStream_t)stream);
+    (void)hipMemsetAsync(col_sums, 0, n_cols * sizeof(float), (hipStream_t)stream);
+    return PINN_OK;
+  }
   const int e = pick_engine(desc, n, &rc); if (rc) return rc;
   return e == PINN_ENGINE_FUSED ? fused_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream)
        : e == PINN_ENGINE_WIDE ? wide_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream)

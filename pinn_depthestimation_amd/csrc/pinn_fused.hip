@@ -101,8 +101,8 @@ __global__ void k_pack(Net n, int WP, const float* __restrict__ params, float* _
   }
 }
 
-__global__ void k_reduce_sums(const float* __restrict__ wg_sums, int grid, int nt, float* __restrict__ out) {
-  const int t = blockIdx.x;
+__global__ void k_reduce_sums(const float* __restrict__ wg_sums, int grid, int col0, int nt, float* __restrict__ out) {
+  const int t = col0 + blockIdx.x;
   __shared__ double red[256];
   double v = 0.0;
   for (int b = threadIdx.x; b < grid; b += 256) v += (double)wg_sums[(int64_t)b * MAX_SUMS + t];
@@ -112,7 +112,7 @@ __global__ void k_reduce_sums(const float* __restrict__ wg_sums, int grid, int n
     if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0 && t < nt) out[t] = (float)red[0];
+  if (threadIdx.x == 0 && blockIdx.x < nt) out[blockIdx.x] = (float)red[0];
 }
 
 // grad_flat[real index] += sum over copies of the padded per-workgroup gradients (fixed order)
@@ -165,20 +165,21 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
   P.acc_lds = (grad && fits_lds(g)) ? 1 : 0;
   P.nrep = NREP;
   P.lds_acc_floats = P.acc_lds ? g.PP : 0;
-  int n_terms = 0;
   if (rq) {
-    P.loss_kind = rq->kind == 1 ? 2 : 1;
-    P.scale = rq->scale;
-    n_terms = rq->n_terms;
-    if (rq->kind == 1) {
-      P.n_cols = rq->n_cols; P.T = rq->T;
-      for (int j = 0; j < PINN_MAX_ROLES; ++j) P.out_col[j] = rq->out_col[j];
-    } else {
+    P.loss_kind = rq->kind == 0 ? 1 : (rq->kind == 1 ? 2 : 3);
+    if (P.loss_kind & 1) {
+      P.scale = rq->scale;
       P.residual_id = rq->spec.residual_id;
       for (int j = 0; j < PINN_MAX_ROLES; ++j) P.out_col[j] = rq->spec.out_col[j];
       for (int d = 0; d < PINN_MAX_DIRS; ++d) P.q_of[d] = 1 + rq->spec.dir_of[d];
       P.thr = rq->spec.param[0]; P.anchor = rq->spec.param[1];
       P.xcol = n.dir_col[rq->spec.dir_of[0]];
+    } else {
+      for (int j = 0; j < PINN_MAX_ROLES; ++j) P.out_col[j] = -1;
+    }
+    if (P.loss_kind & 2) {
+      P.n_cols = rq->n_cols; P.T = rq->T; P.mse_scale = rq->mse_scale;
+      for (int j = 0; j < PINN_MAX_ROLES; ++j) P.mse_col[j] = j < rq->n_cols ? rq->out_col[j] : -1;
     }
   }
   const int grid = grid_for(P.n_tiles, grad && P.acc_lds);
@@ -200,8 +201,12 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
   }
   if (rc) return rc;
   if (rq) {
-    hipLaunchKernelGGL(k_reduce_sums, dim3(n_terms), dim3(256), 0, s, (const float*)P.wg_sums, grid, n_terms,
-                       rq->sums);
+    if (P.loss_kind & 1)
+      hipLaunchKernelGGL(k_reduce_sums, dim3(rq->n_terms), dim3(256), 0, s, (const float*)P.wg_sums, grid, 0,
+                         rq->n_terms, rq->sums);
+    if (P.loss_kind & 2)
+      hipLaunchKernelGGL(k_reduce_sums, dim3(rq->n_cols), dim3(256), 0, s, (const float*)P.wg_sums, grid, MSE_SUM0,
+                         rq->n_cols, rq->mse_sums);
     if (grad) {
       const int copies = P.acc_lds ? grid : NREP;
       const int64_t np = n.n_params();

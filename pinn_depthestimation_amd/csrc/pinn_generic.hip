@@ -380,14 +380,8 @@ int run_loss(const Net& n, const LossReq& rq, const float* params, const float* 
   float* partial = (float*)(ws + lo.partial);
   const bool want_grad = rq.grad != nullptr;
   if (want_grad) (void)hipMemsetAsync(G, 0, (size_t)K1 * n.d_out * N * 4, s);
-  int nt_stride = 0;
-  if (rq.kind == 1) {
-    MseMap mm; mm.n_cols = rq.n_cols;
-    for (int j = 0; j < PINN_MAX_ROLES; ++j) mm.out_col[j] = j < rq.n_cols ? rq.out_col[j] : 0;
-    nt_stride = PINN_MAX_ROLES;
-    if (want_grad) hipLaunchKernelGGL(k_mse<true>, dim3(grid), dim3(TPB), 0, s, out, n.d_out, N, mm, rq.T, rq.scale, G, partial);
-    else hipLaunchKernelGGL(k_mse<false>, dim3(grid), dim3(TPB), 0, s, out, n.d_out, N, mm, rq.T, rq.scale, G, partial);
-  } else {
+  if (rq.kind == 0 || rq.kind == 2) {
+    int nt_stride = 0;
     RoleMap rm;
     for (int r = 0; r < PINN_MAX_ROLES; ++r) rm.out_col[r] = rq.spec.out_col[r];
     for (int d = 0; d < PINN_MAX_DIRS; ++d) rm.q_of[d] = 1 + rq.spec.dir_of[d];
@@ -408,9 +402,17 @@ int run_loss(const Net& n, const LossReq& rq, const float* params, const float* 
     else if (id == PINN_RES_CONTINUITY_ONLY) LAUNCH_RES(ResContinuity, 1, n.dir_col[rq.spec.dir_of[0]]);
     else { set_error("unknown residual_id %d", id); return PINN_ERR_INVALID; }
 #undef LAUNCH_RES
+    hipLaunchKernelGGL(k_reduce_partials, dim3(rq.n_terms), dim3(256), 0, s, (const float*)partial, lo.nblocks,
+                       nt_stride, rq.n_terms, rq.sums);
   }
-  hipLaunchKernelGGL(k_reduce_partials, dim3(rq.n_terms), dim3(256), 0, s, (const float*)partial, lo.nblocks,
-                     nt_stride, rq.n_terms, rq.sums);
+  if (rq.kind == 1 || rq.kind == 2) {   // fidelity columns; adds into G (pre-zeroed / after the residual's writes)
+    MseMap mm; mm.n_cols = rq.n_cols;
+    for (int j = 0; j < PINN_MAX_ROLES; ++j) mm.out_col[j] = j < rq.n_cols ? rq.out_col[j] : 0;
+    if (want_grad) hipLaunchKernelGGL(k_mse<true>, dim3(grid), dim3(TPB), 0, s, out, n.d_out, N, mm, rq.T, rq.mse_scale, G, partial);
+    else hipLaunchKernelGGL(k_mse<false>, dim3(grid), dim3(TPB), 0, s, out, n.d_out, N, mm, rq.T, rq.mse_scale, G, partial);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(rq.n_cols), dim3(256), 0, s, (const float*)partial, lo.nblocks,
+                       PINN_MAX_ROLES, rq.n_cols, rq.mse_sums);
+  }
   rc = check_launch("generic loss");
   if (rc || !want_grad) return rc;
   return run_backward<K1>(n, params, N, ws, lo, rq.grad, s);

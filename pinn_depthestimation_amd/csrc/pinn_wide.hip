@@ -92,15 +92,16 @@ __global__ void k_wide_pack(Net n, int WP, const float* __restrict__ params, flo
   }
 }
 
-__global__ void k_wide_reduce_sums(const float* __restrict__ wg_sums, int64_t rows, int nt, float* __restrict__ out) {
-  const int t = blockIdx.x;
+__global__ void k_wide_reduce_sums(const float* __restrict__ wg_sums, int64_t rows, int col0, int nt,
+                                   float* __restrict__ out) {
+  const int t = col0 + blockIdx.x;
   __shared__ double red[256];
   double v = 0.0;
   for (int64_t b = threadIdx.x; b < rows; b += 256) v += (double)wg_sums[b * MAX_SUMS + t];
   red[threadIdx.x] = v;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
-  if (threadIdx.x == 0 && t < nt) out[t] = (float)red[0];
+  if (threadIdx.x == 0 && blockIdx.x < nt) out[blockIdx.x] = (float)red[0];
 }
 
 template <int NTW>
@@ -112,19 +113,21 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
   for (int j = 0; j < PINN_MAX_DIRS; ++j) P.dir_col[j] = n.dir_col[j];
   P.N = N; P.X = X; P.Y = Y; P.dY = dY;
   P.wg_sums = (float*)(base + w.sums);
-  int n_terms = 0;
   if (rq) {
-    P.loss_kind = rq->kind == 1 ? 2 : 1;
-    P.scale = rq->scale; n_terms = rq->n_terms;
-    if (rq->kind == 1) {
-      P.n_cols = rq->n_cols; P.T = rq->T;
-      for (int j = 0; j < PINN_MAX_ROLES; ++j) P.out_col[j] = rq->out_col[j];
-    } else {
+    P.loss_kind = rq->kind == 0 ? 1 : (rq->kind == 1 ? 2 : 3);
+    if (P.loss_kind & 1) {
+      P.scale = rq->scale;
       P.residual_id = rq->spec.residual_id;
       for (int j = 0; j < PINN_MAX_ROLES; ++j) P.out_col[j] = rq->spec.out_col[j];
       for (int d = 0; d < PINN_MAX_DIRS; ++d) P.q_of[d] = 1 + rq->spec.dir_of[d];
       P.thr = rq->spec.param[0]; P.anchor = rq->spec.param[1];
       P.xcol = n.dir_col[rq->spec.dir_of[0]];
+    } else {
+      for (int j = 0; j < PINN_MAX_ROLES; ++j) P.out_col[j] = -1;
+    }
+    if (P.loss_kind & 2) {
+      P.n_cols = rq->n_cols; P.T = rq->T; P.mse_scale = rq->mse_scale;
+      for (int j = 0; j < PINN_MAX_ROLES; ++j) P.mse_col[j] = j < rq->n_cols ? rq->out_col[j] : -1;
     }
   }
   const float* Wp = (const float*)(base + w.wp);
@@ -195,8 +198,12 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
   }
   if (rc) return rc;
   if (rq) {
-    hipLaunchKernelGGL(k_wide_reduce_sums, dim3(n_terms), dim3(256), 0, s, (const float*)P.wg_sums,
-                       (int64_t)w.n_chunks * w.grid, n_terms, rq->sums);
+    if (P.loss_kind & 1)
+      hipLaunchKernelGGL(k_wide_reduce_sums, dim3(rq->n_terms), dim3(256), 0, s, (const float*)P.wg_sums,
+                         (int64_t)w.n_chunks * w.grid, 0, rq->n_terms, rq->sums);
+    if (P.loss_kind & 2)
+      hipLaunchKernelGGL(k_wide_reduce_sums, dim3(rq->n_cols), dim3(256), 0, s, (const float*)P.wg_sums,
+                         (int64_t)w.n_chunks * w.grid, MSE_SUM0, rq->n_cols, rq->mse_sums);
   }
   return check_launch("wide reductions");
 }

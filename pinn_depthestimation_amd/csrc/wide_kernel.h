@@ -125,23 +125,8 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_fwd(const FusedParams 
   float sums[MAX_SUMS];
 #pragma unroll
   for (int j = 0; j < MAX_SUMS; ++j) sums[j] = 0.f;
-  ScatterMap<K1> sm;
-  if constexpr (LAST) {
-    const int n_roles = P.loss_kind == 2 ? P.n_cols : PINN_MAX_ROLES;
-#pragma unroll
-    for (int r2 = 0; r2 < 4; ++r2) {
-      int ro = -1;
-      for (int r = PINN_MAX_ROLES - 1; r >= 0; --r) ro = (r < n_roles && P.out_col[r] == 4 * q + r2) ? r : ro;
-      sm.role_of[r2] = ro;
-    }
-    sm.cinv[0] = 0;
-#pragma unroll
-    for (int ce = 1; ce < K1; ++ce) {
-      int ci = -1;
-      for (int d = PINN_MAX_DIRS - 1; d >= 0; --d) ci = (P.q_of[d] == ce) ? 1 + d : ci;
-      sm.cinv[ce] = ci;
-    }
-  }
+  ScatterMap<K1> sm, sm_mse;
+  if constexpr (LAST) build_scatter_maps<K1>(P, q, sm, sm_mse);
   const int gw = blockIdx.x * WIDE_WAVES + wave, nw = gridDim.x * WIDE_WAVES;
   for (int64_t t = gw; t < Lp.n_tiles; t += nw) {
     const int64_t pt = (Lp.tile0 + t) * 16 + p;
@@ -178,47 +163,8 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_fwd(const FusedParams 
     } else {
       static_assert(!LAST || NTO == 1, "the output layer has one (padded) tile");
       f4 (&out)[K1][1] = acc;
-      if (P.Y != nullptr && valid) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int o = 4 * q + r;
-          if (o < P.d_out) {
-            P.Y[pt * P.d_out + o] = out[0][0][r];
-            if (P.dY != nullptr) {
-#pragma unroll
-              for (int c = 1; c < K1; ++c) P.dY[((int64_t)(c - 1) * P.N + pt) * P.d_out + o] = out[c][0][r];
-            }
-          }
-        }
-      }
       f4 G[K1][1];
-#pragma unroll
-      for (int c = 0; c < K1; ++c) G[c][0] = f4{0.f, 0.f, 0.f, 0.f};
-      if (P.loss_kind == 1) {
-        if (P.residual_id == PINN_RES_NAVIER_STOKES) {
-          if constexpr (K1 >= 4) residual_tile<ResNavierStokes, K1, GRAD>(P, out, G, sums, sm, tb, valid, false, p, q);
-        } else if (P.residual_id == PINN_RES_PHYSICS_EQUATION) {
-          if constexpr (K1 >= 3) residual_tile<ResPhysicsEquation, K1, GRAD>(P, out, G, sums, sm, tb, valid, false, p, q);
-        } else {
-          if constexpr (K1 >= 3) {
-            const bool masked = P.residual_id == PINN_RES_CONTINUITY_ONLY && P.X[ptc * P.d_in + P.xcol] < P.thr;
-            residual_tile<ResContinuity, K1, GRAD>(P, out, G, sums, sm, tb, valid, masked, p, q);
-          }
-        }
-      } else if (P.loss_kind == 2) {
-        float gm[1][PINN_MAX_ROLES];
-#pragma unroll
-        for (int j = 0; j < PINN_MAX_ROLES; ++j) {
-          gm[0][j] = 0.f;
-          if (j < P.n_cols) {
-            const float y = gather_out(out[0][0], P.out_col[j], p);
-            const float d = P.T[ptc * P.n_cols + j] - y;
-            if (valid && q == 0) sums[j] += d * d;
-            if (GRAD) gm[0][j] = -2.f * P.scale[j] * d;
-          }
-        }
-        if constexpr (GRAD) scatter_adjoint<K1, 1, PINN_MAX_ROLES>(tb, gm, sm, G, valid, p, q);
-      }
+      loss_epilogue<K1, GRAD>(P, out, G, sums, sm, sm_mse, tb, pt, ptc, valid, p, q);
       if constexpr (GRAD) {
 #pragma unroll
         for (int c = 0; c < K1; ++c) *reinterpret_cast<f4*>(Lp.g_out + ((t * K1 + c) * 1 + 0) * 256 + lane * 4) = G[c][0];

@@ -42,6 +42,11 @@ class HipEvaluator:
         self.spec, self.fid_cols = spec, list(fid_cols)
 
     def __call__(self, theta, Xf, Tf, fid_scale, Xr, res_scale, grad, fid_sums, res_sums):
+        if Xf is not None and Xf is Xr and Xr.shape[0] > 0:
+            # one point set for both terms (train_newmethod.py:122-159): one pass, one forward
+            self.eng.residual_mse_loss_grad(self.spec, res_scale, Tf, self.fid_cols, fid_scale, theta, Xr, grad,
+                                            term_sums=res_sums, col_sums=fid_sums)
+            return
         if Xf is not None and Xf.shape[0] > 0:
             self.eng.mse_loss_grad(theta, Xf, Tf, self.fid_cols, fid_scale, grad, sums=fid_sums)
         else:
@@ -87,9 +92,14 @@ class PINN:
         self.weight_fidelity, self.weight_residual = cfg.weight_fid, cfg.weight_res
 
         Xf, Tf, Xr = (_as_f32(a, self.device) for a in (fidelity_input, fidelity_true, residual_input))
+        if Xf is not None and Xr is not None and (fidelity_input is residual_input or
+                                                  (cfg.variant == "newmethod" and Xf.shape == Xr.shape and torch.equal(Xf, Xr))):
+            Xf = Xr            # the same point set: the evaluator fuses both loss terms into one pass
         self.n_fid = 0 if Xf is None else Xf.shape[0]
         self.n_res = 0 if Xr is None else Xr.shape[0]
-        self.Xf, self.Tf, self.Xr = self.reducer.shard(Xf), self.reducer.shard(Tf), self.reducer.shard(Xr)
+        self.Xr = self.reducer.shard(Xr)
+        self.Xf = self.Xr if Xf is Xr else self.reducer.shard(Xf)
+        self.Tf = self.reducer.shard(Tf)
         nf, nt = len(self.fid_cols), self.spec.n_terms
         dev = self.device
         self._fid_unit = torch.tensor(fid_w, dtype=torch.float32, device=dev) / max(self.n_fid, 1)

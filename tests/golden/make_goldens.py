@@ -251,7 +251,7 @@ def g9():
     save("g9_newmethod_at50k.npz", **out)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     os.chdir("/tmp")
     m0 = g1_g2_g3()
     pe_case([2] + [64] * 8 + [6], 256, 44, True, "g4_pe_8x64_conditioned.npz")
@@ -260,3 +260,34 @@ if __name__ == "__main__":
     g6()
     g9()
     g7_g8(m0)
+
+
+def g7b_long():
+    """G7b: 1000 Adam steps (lr 1e-4, StepLR 250/0.8), Navier_Stokes 8x64, N = 4096: how far the
+    trajectories stay together.  Run separately: python make_goldens.py g7b"""
+    z = np.load(os.path.join(OUT, "g1_g3_ns_8x64.npz"))
+    model = ref_dnn.DNN([3] + [64] * 8 + [4], 0.0, "xavier")
+    model.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")})
+    rng = np.random.RandomState(707)
+    X = rng.uniform(-1, 1, size=(4096, 3)).astype(np.float32)
+    c = cols_of(X, (0, 1, 2))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    sch = torch.optim.lr_scheduler.StepLR(opt, step_size=250, gamma=0.8)
+    losses = []
+    for i in range(1000):
+        opt.zero_grad()
+        Y = model(torch.cat(c, dim=-1))
+        h, zz, u, v = [Y[:, j:j + 1] for j in range(4)]
+        loss = ref_physics.Navier_Stokes(c[0], c[1], c[2], h, zz, u, v)
+        loss.backward()
+        opt.step()
+        sch.step()
+        losses.append(loss.item())
+        if i % 100 == 0:
+            print("g7b", i, losses[-1], flush=True)
+    save("g7b_adam_1000_ns_8x64.npz", X=X, losses=np.array(losses, np.float64))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "g7b":
+    os.chdir("/tmp")
+    g7b_long()

@@ -174,3 +174,26 @@ def test_adam_step_matches_torch():
         opt.step(); sch.step()
         eng.adam_step(pd, gr.cuda(), m, v, step, lr)
         assert torch.equal(pd.cpu(), ref.detach()), f"step {step}: max diff {(pd.cpu()-ref.detach()).abs().max()}"
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_residual_and_mse_in_one_pass(engine):
+    """pinn_residual_mse_loss_grad (train_newmethod.py:122-159: one forward feeds both terms) equals the
+    two separate calls on the same points."""
+    layers, params, X, desc, res, inn, outn = make_case("co_4x20", 555)
+    X[:, 0] = X[:, 0] * 40
+    g = torch.Generator().manual_seed(8)
+    T = torch.rand(555, 2, generator=g).cuda()
+    eng = Engine(desc.with_(engine=engine))
+    spec = ResidualSpec.from_names(res, inn, desc.grad_cols, outn)
+    flat, Xd = O.flatten(params).cuda(), X.cuda().contiguous()
+    cnt = float((X[:, 0] < 25.5).sum())
+    ts = torch.tensor([1.0 / 555, 1.0 / cnt, 0.0]).cuda()
+    cs = torch.tensor([0.7 / 555, 1.3 / 555]).cuda()
+    g1 = torch.zeros(desc.n_params, device="cuda")
+    s_res = eng.residual_loss_grad(spec, ts, flat, Xd, g1)
+    s_mse = eng.mse_loss_grad(flat, Xd, T, [0, 1], cs, g1)
+    g2 = torch.zeros(desc.n_params, device="cuda")
+    t_sums, c_sums = eng.residual_mse_loss_grad(spec, ts, T, [0, 1], cs, flat, Xd, g2)
+    assert torch.allclose(t_sums, s_res, rtol=1e-6) and torch.allclose(c_sums, s_mse, rtol=1e-6)
+    assert rel_l2(g2.cpu(), g1.cpu()) < 2e-6
