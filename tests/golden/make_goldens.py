@@ -21,6 +21,7 @@ G7  train.py:188-193 loop, 200 steps of Adam(1e-4)+StepLR(step 50, gamma .8), Na
     N = 10000: loss trajectory + final weights
 G8  train.py:195-200: ONE torch.optim.LBFGS.step (history 100, strong_wolfe, tol 1e-5/1e-7,
     max_iter 50) from the G7 end state, N = 2000: every closure loss + final weights
+G7b the same loop for 1000 steps (StepLR 250 / 0.8), N = 4096: loss trajectory only (`python make_goldens.py g7b`)
 G9  train_newmethod.py:120-159 arithmetic on data_at50k.mat's pred_U/pred_V as `trues`
     (2->100x20->3 and 2->8x64->3, continuity_only), seeded synthetic (x,y): 5 Adam steps
 """

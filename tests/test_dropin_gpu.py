@@ -228,8 +228,8 @@ def test_cpu_tensor_is_refused_loudly():
 
 def test_g7b_adam_trajectory_1000_steps():
     """Longer horizon than G7: 1000 Adam steps (StepLR 250 / 0.8), N = 4096, against the reference's own
-    CPU run.  Rounding differences grow along an optimisation trajectory; observed max 3e-5 over the
-    1000 steps, asserted 2e-4 (north_star's 1e-5 holds over the first 200 steps, see G7)."""
+    CPU run.  Observed max relative difference 3.5e-6 over the 1000 steps; asserted 1e-5
+    (BASELINE north_star: "loss within 1e-5 rel of reference")."""
     from pinn_depthestimation_amd.trainer import pinn
     import dnn
     z0, z = load("g1_g3_ns_8x64.npz"), load("g7b_adam_1000_ns_8x64.npz")
@@ -241,5 +241,4 @@ def test_g7b_adam_trajectory_1000_steps():
     ref = z["losses"]
     rel = np.abs(got - ref) / ref
     print("1000-step trajectory rel err: max %.2e | @200 %.2e | @500 %.2e | @1000 %.2e" % (rel.max(), rel[:200].max(), rel[:500].max(), rel[-1]))
-    assert rel[:200].max() < 1e-5
-    assert rel.max() < 2e-4
+    assert rel.max() < 1e-5
