@@ -24,7 +24,7 @@ def test_train_then_test_like_the_reference_scripts(tmp_path):
     fid = pd.DataFrame({"x": xs.ravel(), "y": ys.ravel(), "h": h.ravel(), "U": U.ravel(), "V": V.ravel(),
                         "eta_mean": 0.01 * np.sin(xs.ravel()), "Hrms": 0.2 + 0 * xs.ravel(), "k": 1.0 + 0 * xs.ravel()})
     fid.sample(400, random_state=1).to_csv(tmp_path / "input_fid.csv", index=False)
-    xr = xs.copy(); xr[3, 7] = np.nan                                   # one NaN cell, dropped by the mask (train.py:276-277)
+    xr = xs.copy(); xr[10, 20] = np.nan                                 # one NaN cell, dropped by the mask (train.py:276-277)
     savemat(tmp_path / "input_res.mat", {"x": xr, "y": ys})
     cfg = {
         "layers": {"input_features": 2, "hidden_layers": 10, "hidden_width": 10, "output_features": 6,
