@@ -549,7 +549,7 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
     gemm_chain<1, NTH, K1>(w0, b0, a);
     PINN_STAMP(0);
     activate<ACT, NTH, K1>(a);
-    if (GRAD) spill<NTH, K1>(scr, a, lane);
+    if (GRAD && L > 1) spill<NTH, K1>(scr, a, lane);      // a_L itself stays in registers for the reverse sweep
     PINN_STAMP(1);
     for (int l = 1; l < L; ++l) {
       f4 wn[NTH][NTH];
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
       gemm_chain<NTH, NTH, K1>(wh, a, nx);
       PINN_STAMP(0);
       activate<ACT, NTH, K1>(nx);
-      if (GRAD) spill<NTH, K1>(scr + l * SLOT, nx, lane);
+      if (GRAD && l < L - 1) spill<NTH, K1>(scr + l * SLOT, nx, lane);   // (the last hidden jet is never re-read)
       PINN_STAMP(1);
       copy_tiles<NTH, K1>(a, nx);
       copy_w<NTH, NTH>(wh, wn);

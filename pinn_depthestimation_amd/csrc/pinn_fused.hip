@@ -115,29 +115,38 @@ __global__ void k_reduce_sums(const float* __restrict__ wg_sums, int grid, int c
   if (threadIdx.x == 0 && blockIdx.x < nt) out[blockIdx.x] = (float)red[0];
 }
 
-// grad_flat[real index] += sum over copies of the padded per-workgroup gradients (fixed order)
+// grad_flat[real index] += sum over copies of the padded per-workgroup gradients.  64 parameters x
+// 4 copy groups per block; each thread adds its group's copies in index order and the 4 partial sums
+// are combined in a fixed order, so the result does not depend on scheduling.
 __global__ void k_reduce_grads(Net n, int WP, const float* __restrict__ wg, int copies, int PP, int PW,
                                float* __restrict__ grad) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n.n_params()) return;
-  int l = 0; int64_t off = 0;
-  for (;; ++l) {
-    const int64_t sz = (int64_t)n.in_dim(l) * n.out_dim(l) + n.out_dim(l);
-    if (i < off + sz) break;
-    off += sz;
-  }
-  const int64_t r = i - off;
-  const int in_d = n.in_dim(l), out_d = n.out_dim(l);
-  const int inP = (l == 0) ? 16 : WP;
-  const int wo = (l == 0) ? 0 : WP * 16 + (l - 1) * WP * WP;
-  int pidx;
-  if (r < (int64_t)in_d * out_d) {   // fragment-native block layout (fused_kernel.h, GradSink)
-    const int row = (int)(r / in_d), col = (int)(r % in_d), ntn = inP / 16;
-    pidx = wo + (((row >> 4) * ntn + (col >> 4)) * 64 + ((row & 15) >> 2) * 16 + (col & 15)) * 4 + (row & 3);
-  } else pidx = PW + l * WP + (int)(r - (int64_t)in_d * out_d);
+  __shared__ float part[4][64];
+  const int lane_p = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane_p;
   float s = 0.f;
-  for (int c = 0; c < copies; ++c) s += wg[(int64_t)c * PP + pidx];
-  grad[i] += s;
+  if (i < n.n_params()) {
+    int l = 0; int64_t off = 0;
+    for (;; ++l) {
+      const int64_t sz = (int64_t)n.in_dim(l) * n.out_dim(l) + n.out_dim(l);
+      if (i < off + sz) break;
+      off += sz;
+    }
+    const int64_t r = i - off;
+    const int in_d = n.in_dim(l), out_d = n.out_dim(l);
+    const int inP = (l == 0) ? 16 : WP;
+    const int wo = (l == 0) ? 0 : WP * 16 + (l - 1) * WP * WP;
+    int pidx;
+    if (r < (int64_t)in_d * out_d) {   // fragment-native block layout (fused_kernel.h, GradSink)
+      const int row = (int)(r / in_d), col = (int)(r % in_d), ntn = inP / 16;
+      pidx = wo + (((row >> 4) * ntn + (col >> 4)) * 64 + ((row & 15) >> 2) * 16 + (col & 15)) * 4 + (row & 3);
+    } else pidx = PW + l * WP + (int)(r - (int64_t)in_d * out_d);
+    const int per = (copies + 3) / 4;
+    const int c0 = grp * per, c1 = (c0 + per < copies) ? c0 + per : copies;
+    for (int c = c0; c < c1; ++c) s += wg[(int64_t)c * PP + pidx];
+  }
+  part[grp][lane_p] = s;
+  __syncthreads();
+  if (grp == 0 && i < n.n_params()) grad[i] += (part[0][lane_p] + part[1][lane_p]) + (part[2][lane_p] + part[3][lane_p]);
 }
 
 int run(const Net& n, bool grad, const LossReq* rq, const float* params, const float* X, int64_t N, float* Y,
@@ -210,7 +219,7 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
     if (grad) {
       const int copies = P.acc_lds ? grid : NREP;
       const int64_t np = n.n_params();
-      hipLaunchKernelGGL(k_reduce_grads, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, n, g.WP,
+      hipLaunchKernelGGL(k_reduce_grads, dim3((unsigned)((np + 63) / 64)), dim3(256), 0, s, n, g.WP,
                          (const float*)P.wg_grads, copies, g.PP, g.PW, rq->grad);
     }
   }
