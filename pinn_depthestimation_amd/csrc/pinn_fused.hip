@@ -35,7 +35,10 @@ int cu_count() {
 }
 
 constexpr int64_t LDS_LIMIT = 160 * 1024;
-constexpr int NREP = 16;   // replicated global accumulators when the gradient does not fit LDS
+#ifndef PINN_NREP
+#define PINN_NREP 16
+#endif
+constexpr int NREP = PINN_NREP;   // replicated global accumulators when the gradient does not fit LDS
 
 int64_t lds_fixed_bytes() { return (int64_t)(MAX_LOCKS + FUSED_WAVES * TB_PER_WAVE * TB_FLOATS + FUSED_WAVES * MAX_SUMS) * 4; }
 bool fits_lds(const Geo& g) { return (int64_t)g.PP * 4 + lds_fixed_bytes() <= LDS_LIMIT; }
@@ -191,8 +194,11 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
       for (int j = 0; j < PINN_MAX_ROLES; ++j) P.mse_col[j] = j < rq->n_cols ? rq->out_col[j] : -1;
     }
   }
-  const int grid = grid_for(P.n_tiles, grad && P.acc_lds);
   const size_t lds = (size_t)P.lds_acc_floats * 4 + (size_t)lds_fixed_bytes();
+  // 8x64 gradient kernels fill the register file and most of LDS (1 workgroup per CU); the narrow
+  // networks' kernels fit 2 waves per SIMD, which hides their per-layer latencies
+  const bool one_per_cu = grad && P.acc_lds && !(g.WP <= 32 && 2 * (int64_t)lds <= LDS_LIMIT);
+  const int grid = grid_for(P.n_tiles, one_per_cu);
 
   const int packN = g.PW > g.PB ? g.PW : g.PB;
   hipLaunchKernelGGL(k_pack, dim3((packN + 255) / 256), dim3(256), 0, s, n, g.WP, params, (float*)(base + w.wp),
