@@ -33,13 +33,14 @@ constexpr int64_t ACT_BUDGET_BYTES = (int64_t)6 << 30;   // activation workspace
 
 struct WLayout {
   int64_t chunk_pts, chunk_tiles, n_chunks;
-  int64_t wp, wtp, bp, wp16, wtp16, act, act_stride, gA, gB, gout, sums, total;
+  int64_t wp, wtp, bp, wp16, wtp16, act, act_stride, gA, gB, gZ, gout, sums, total;
   int grid;
 };
 WLayout wlayout(const Net& n, const WGeo& g, int64_t N) {
   WLayout w;
   const int K1 = 1 + PINN_MAX_DIRS;
-  const int64_t per_pt = (int64_t)K1 * g.WP * 4 * (n.L + 2) + (int64_t)K1 * 16 * 4;
+  // L jets + 2 adjoint buffers (+1 zbar buffer in bf16 mode, where two waves share a tile)
+  const int64_t per_pt = (int64_t)K1 * g.WP * 4 * (n.L + 2 + (n.prec == PINN_PREC_BF16 ? 1 : 0)) + (int64_t)K1 * 16 * 4;
   // whole number of tiles per wave in every full chunk (no tail imbalance): multiple of waves * 16 points
   const int64_t quantum = (int64_t)cus() * WIDE_WAVES * 16;
   int64_t cp = ACT_BUDGET_BYTES / per_pt;
@@ -59,6 +60,7 @@ WLayout wlayout(const Net& n, const WGeo& g, int64_t N) {
   w.act = off; off += w.act_stride * n.L;
   w.gA = off; off += w.act_stride;
   w.gB = off; off += w.act_stride;
+  w.gZ = off; off += (n.prec == PINN_PREC_BF16) ? w.act_stride : 0;
   w.gout = off; off += al256(w.chunk_tiles * K1 * 256 * 4);
   w.sums = off; off += al256(w.n_chunks * w.grid * MAX_SUMS * 4);
   w.total = off;
@@ -144,6 +146,7 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
   auto act_l = [&](int l) { return (float*)(base + w.act + (int64_t)(l - 1) * w.act_stride); };   // a_l, l = 1..L
   float* gA = (float*)(base + w.gA);
   float* gB = (float*)(base + w.gB);
+  float* gZ = (float*)(base + w.gZ);
   float* gout = (float*)(base + w.gout);
   const int K1 = n.K1, L = n.L;
   const int64_t total_tiles = (N + 15) / 16;
@@ -183,16 +186,18 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
     for (int l = L - 1; l >= 1; --l) {
       // zbar_l (in place over gcur) and abar_l = W_l^T zbar_l
       Lp.W = WTp + woff(l); Lp.W16 = WTp16 + woff(l); Lp.g_in = gcur; Lp.in_act = act_l(l + 1); Lp.g_out = gnext;
+      float* zdst = (prec == PINN_PREC_BF16) ? gZ : gcur;   // fp32: one wave per tile -> in place
+      Lp.z_out = zdst;
       rc = launch_wide_bwd<NTW>(1, K1, prec, P, Lp, grid, s); if (rc) break;
-      Lp.in_act = act_l(l); Lp.in_d = n.in_dim(l); Lp.out_d = n.out_dim(l);
+      Lp.g_in = zdst; Lp.in_act = act_l(l); Lp.in_d = n.in_dim(l); Lp.out_d = n.out_dim(l);
       Lp.dW = rq->grad + n.w_off(l); Lp.db = rq->grad + n.b_off(l);
       rc = launch_wide_wgrad<NTW>(1, K1, prec, P, Lp, gx_h, s); if (rc) break;
       float* t = gcur; gcur = gnext; gnext = t;
     }
     if (rc) break;
-    Lp.g_in = gcur; Lp.in_act = act_l(1); Lp.g_out = nullptr; Lp.W = nullptr;
+    Lp.g_in = gcur; Lp.in_act = act_l(1); Lp.g_out = nullptr; Lp.W = nullptr; Lp.z_out = gcur;
     rc = launch_wide_bwd<NTW>(0, K1, prec, P, Lp, grid, s); if (rc) break;
-    Lp.in_act = nullptr; Lp.in_d = n.in_dim(0); Lp.out_d = n.out_dim(0);
+    Lp.g_in = gcur; Lp.in_act = nullptr; Lp.in_d = n.in_dim(0); Lp.out_d = n.out_dim(0);
     Lp.dW = rq->grad + n.w_off(0); Lp.db = rq->grad + n.b_off(0);
     rc = launch_wide_wgrad<NTW>(0, K1, prec, P, Lp, gx_h, s); if (rc) break;
   }

@@ -32,6 +32,7 @@ struct WideLayer {
   float* out_act;        // fwd: layer output jet
   float* g_in;           // bwd: adjoint of the layer output (overwritten with zbar); wgrad: zbar
   float* g_out;          // bwd: adjoint of the layer input
+  float* z_out;          // bwd: zbar (activation adjoint applied), read by wgrad as g_in
   float* dW;             // wgrad: flat torch-layout gradient of this layer's weight (out_d x in_d)
   float* db;             // wgrad: gradient of this layer's bias
   int in_d, out_d;       // real (unpadded) dims of the layer
@@ -113,11 +114,19 @@ __device__ __forceinline__ void wide_input_jet(const FusedParams& P, int64_t ptc
 
 // out = act(W . in + b) for one layer.  FIRST: the input is (x, unit tangents) built from X.
 // LAST: no activation; outputs / loss / output adjoint instead of a stored jet.
-template <int NTI, int NTO, int K1, int ACT, bool FIRST, bool LAST, bool GRAD, bool BF16>
-__global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_fwd(const FusedParams P, const WideLayer Lp) {
+// HV = 2: the output tiles of one 16-point tile are split between two waves (NTO/2 accumulator tiles
+// = 128 registers each), so two waves fit per SIMD and cover each other's load latencies; both read
+// the same input jet (second read served by L1/L2).
+template <int NTI, int NTO_ALL, int K1, int ACT, bool FIRST, bool LAST, bool GRAD, bool BF16, int HV = 1>
+__global__ __launch_bounds__(WIDE_THREADS * HV, HV) void k_wide_fwd(const FusedParams P, const WideLayer Lq) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) / HV, hf = (threadIdx.x >> 6) % HV;
   const int p = lane & 15, q = lane >> 4;
+  constexpr int NTO = NTO_ALL / HV;
+  WideLayer Lp = Lq;
+  Lp.W = Lq.W + hf * NTO * 16 * (16 * NTI);
+  Lp.W16 = Lq.W16 + hf * NTO * 16 * (16 * NTI);
+  Lp.b = Lq.b + hf * NTO * 16;
   float* tb = smem + wave * (WIDE_MAX_PADS * TB_FLOATS);
   float* lsum = smem + WIDE_WAVES * WIDE_MAX_PADS * TB_FLOATS;
   constexpr int CH = NTI < 4 ? NTI : 4;
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_fwd(const FusedParams 
       for (int c = 0; c < K1; ++c)
 #pragma unroll
         for (int MT = 0; MT < NTO; ++MT)
-          *reinterpret_cast<f4*>(Lp.out_act + ((t * K1 + c) * NTO + MT) * 256 + lane * 4) = acc[c][MT];
+          *reinterpret_cast<f4*>(Lp.out_act + ((t * K1 + c) * NTO_ALL + hf * NTO + MT) * 256 + lane * 4) = acc[c][MT];
     } else {
       static_assert(!LAST || NTO == 1, "the output layer has one (padded) tile");
       f4 (&out)[K1][1] = acc;
@@ -191,13 +200,26 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_fwd(const FusedParams 
 
 // zbar = adjoint through the activation (HIDDEN; written back over g_in), abar_in = W^T zbar (NEED_GIN).
 // NTK = tiles of the layer OUTPUT (the contraction axis here), NTO = tiles of the layer INPUT.
-template <int NTK, int NTO, int K1, int ACT, bool HIDDEN, bool NEED_GIN, bool BF16>
-__global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_bwd(const FusedParams P, const WideLayer Lp) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// HV = 2 as in k_wide_fwd (input-feature tiles split between two waves).  zbar goes to z_out, never
+// back over g_in: with two waves per tile an in-place update would be read twice.
+template <int NTK, int NTO_ALL, int K1, int ACT, bool HIDDEN, bool NEED_GIN, bool BF16, int HV = 1>
+__global__ __launch_bounds__(WIDE_THREADS * HV, HV) void k_wide_bwd(const FusedParams P, const WideLayer Lq) {
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) / HV, hf = (threadIdx.x >> 6) % HV;
   const int p = lane & 15, q = lane >> 4;
+  constexpr int NTO = NTO_ALL / HV;
+  WideLayer Lp = Lq;
+  if (NEED_GIN) {
+    Lp.W = Lq.W + hf * NTO * 16 * (16 * NTK);
+    Lp.W16 = Lq.W16 + hf * NTO * 16 * (16 * NTK);
+  }
   constexpr int CH = NTK < 4 ? NTK : 4;
   constexpr int LDW = 16 * NTK;
   const int gw = blockIdx.x * WIDE_WAVES + wave, nw = gridDim.x * WIDE_WAVES;
+  // local restrict-qualified views: the jets, the incoming adjoint and the two outputs never overlap
+  const float* __restrict__ gin_p = Lp.g_in;
+  const float* __restrict__ act_p = Lp.in_act;
+  float* __restrict__ zout_p = (HV == 1) ? Lp.g_in : Lp.z_out;
+  float* __restrict__ gout_p = Lp.g_out;
   for (int64_t t = gw; t < Lp.n_tiles; t += nw) {
     f4 acc[K1][NTO];
     zero_tiles<NTO, K1>(acc);
@@ -207,20 +229,25 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_bwd(const FusedParams 
       for (int c = 0; c < K1; ++c)
 #pragma unroll
         for (int j = 0; j < CH; ++j)
-          g[c][j] = *reinterpret_cast<const f4*>(Lp.g_in + ((t * K1 + c) * NTK + kc + j) * 256 + lane * 4);
+          g[c][j] = *reinterpret_cast<const f4*>((HV == 1 ? Lp.g_in : gin_p) + ((t * K1 + c) * NTK + kc + j) * 256 + lane * 4);
       if constexpr (HIDDEN) {
         f4 ao[K1][CH];
 #pragma unroll
         for (int c = 0; c < K1; ++c)
 #pragma unroll
           for (int j = 0; j < CH; ++j)
-            ao[c][j] = *reinterpret_cast<const f4*>(Lp.in_act + ((t * K1 + c) * NTK + kc + j) * 256 + lane * 4);
+            ao[c][j] = *reinterpret_cast<const f4*>(act_p + ((t * K1 + c) * NTK + kc + j) * 256 + lane * 4);
         activate_adjoint<ACT, CH, K1>(g, ao);
+        // HV == 1: in place through the SAME pointer the loads use (the compiler then knows the store
+        // cannot alias the next chunk's loads); HV == 2: separate buffer, written by one of the two waves
+        float* zdst = (HV == 1) ? Lp.g_in : zout_p;
+        if (hf == 0) {
 #pragma unroll
-        for (int c = 0; c < K1; ++c)
+          for (int c = 0; c < K1; ++c)
 #pragma unroll
-          for (int j = 0; j < CH; ++j)
-            *reinterpret_cast<f4*>(Lp.g_in + ((t * K1 + c) * NTK + kc + j) * 256 + lane * 4) = g[c][j];
+            for (int j = 0; j < CH; ++j)
+              *reinterpret_cast<f4*>(zdst + ((t * K1 + c) * NTK + kc + j) * 256 + lane * 4) = g[c][j];
+        }
       }
       if constexpr (NEED_GIN) wide_mac_chunk<CH, K1, NTO, BF16>(Lp, kc, LDW, p, q, g, acc);
     }
@@ -229,7 +256,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_bwd(const FusedParams 
       for (int c = 0; c < K1; ++c)
 #pragma unroll
         for (int MT = 0; MT < NTO; ++MT)
-          *reinterpret_cast<f4*>(Lp.g_out + ((t * K1 + c) * NTO + MT) * 256 + lane * 4) = acc[c][MT];
+          *reinterpret_cast<f4*>(gout_p + ((t * K1 + c) * NTO_ALL + hf * NTO + MT) * 256 + lane * 4) = acc[c][MT];
     }
   }
 }
