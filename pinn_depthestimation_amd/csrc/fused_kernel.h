@@ -513,7 +513,12 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
   ScatterMap<K1> sm, sm_mse;
   build_scatter_maps<K1>(P, q, sm, sm_mse);
   const int gw = blockIdx.x * FUSED_WAVES + wave, nw = gridDim.x * FUSED_WAVES;
-  float* scr = P.scratch + (int64_t)gw * P.scratch_per_wave;
+  // restrict-qualified views: weights / biases / inputs are read-only for the whole launch and the
+  // spill slot is private to this wave, so loads may be scheduled across the spill stores
+  float* __restrict__ scr = P.scratch + (int64_t)gw * P.scratch_per_wave;
+  const float* __restrict__ Wp_ = P.Wp;
+  const float* __restrict__ WTp_ = P.WTp;
+  const float* __restrict__ Bp_ = P.Bp;
   constexpr int SLOT = K1 * NTH * 256;  // floats per spilled layer
   const int L = P.L;
 
@@ -539,13 +544,13 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
     input_jet(b0);
     // ---- forward chain (weights of layer l+1 are fetched while layer l computes) -------------
     f4 w0[NTH][1];
-    load_w<1, NTH>(P.Wp, w0, p, q);
+    load_w<1, NTH>(Wp_, w0, p, q);
     f4 wh[NTH][NTH];
-    load_w<NTH, NTH>(P.Wp + w_off_p<WP>(L > 1 ? 1 : 0), wh, p, q);      // L == 1: dummy in-bounds read, unused
+    load_w<NTH, NTH>(Wp_ + w_off_p<WP>(L > 1 ? 1 : 0), wh, p, q);      // L == 1: dummy in-bounds read, unused
     f4 wl[1][NTH];
-    load_w<NTH, 1>(P.Wp + w_off_p<WP>(L), wl, p, q);
+    load_w<NTH, 1>(Wp_ + w_off_p<WP>(L), wl, p, q);
     f4 a[K1][NTH];
-    init_bias<NTH, K1>(P.Bp + b_off_p<WP>(0), a, q);
+    init_bias<NTH, K1>(Bp_ + b_off_p<WP>(0), a, q);
     gemm_chain<1, NTH, K1>(w0, b0, a);
     PINN_STAMP(0);
     activate<ACT, NTH, K1>(a);
@@ -553,9 +558,9 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
     PINN_STAMP(1);
     for (int l = 1; l < L; ++l) {
       f4 wn[NTH][NTH];
-      load_w<NTH, NTH>(P.Wp + w_off_p<WP>(l + 1 < L ? l + 1 : l), wn, p, q);   // prefetch (last: redundant, in bounds)
+      load_w<NTH, NTH>(Wp_ + w_off_p<WP>(l + 1 < L ? l + 1 : l), wn, p, q);   // prefetch (last: redundant, in bounds)
       f4 nx[K1][NTH];
-      init_bias<NTH, K1>(P.Bp + b_off_p<WP>(l), nx, q);
+      init_bias<NTH, K1>(Bp_ + b_off_p<WP>(l), nx, q);
       gemm_chain<NTH, NTH, K1>(wh, a, nx);
       PINN_STAMP(0);
       activate<ACT, NTH, K1>(nx);
@@ -565,15 +570,15 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
       copy_w<NTH, NTH>(wh, wn);
     }
     f4 out[K1][1];
-    init_bias<1, K1>(P.Bp + b_off_p<WP>(L), out, q);
+    init_bias<1, K1>(Bp_ + b_off_p<WP>(L), out, q);
     gemm_chain<NTH, 1, K1>(wl, a, out);
     // reverse-sweep operands whose latency the residual evaluation below hides
     f4 wtl[NTH][1];
     f4 wt[NTH][NTH];
     f4 ai[K1][NTH];
     if constexpr (GRAD) {
-      load_w<1, NTH>(P.WTp + w_off_p<WP>(L), wtl, p, q);
-      load_w<NTH, NTH>(P.WTp + w_off_p<WP>(L > 1 ? L - 1 : 0), wt, p, q);
+      load_w<1, NTH>(WTp_ + w_off_p<WP>(L), wtl, p, q);
+      load_w<NTH, NTH>(WTp_ + w_off_p<WP>(L > 1 ? L - 1 : 0), wt, p, q);
       unspill<NTH, K1>(scr + (L > 1 ? L - 2 : 0) * SLOT, ai, lane);            // a_{L-1}
     }
 
@@ -604,7 +609,7 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
         f4 an[K1][NTH];
         f4 wtn[NTH][NTH];
         unspill<NTH, K1>(scr + (l >= 2 ? l - 2 : 0) * SLOT, an, lane);            // a_{l-1} for the next iteration
-        load_w<NTH, NTH>(P.WTp + w_off_p<WP>(l >= 2 ? l - 1 : 1), wtn, p, q);
+        load_w<NTH, NTH>(WTp_ + w_off_p<WP>(l >= 2 ? l - 1 : 1), wtn, p, q);
         f4 g2[K1][NTH];
         zero_tiles<NTH, K1>(g2);
         gemm_chain<NTH, NTH, K1>(wt, g, g2);

@@ -197,3 +197,38 @@ def test_residual_and_mse_in_one_pass(engine):
     t_sums, c_sums = eng.residual_mse_loss_grad(spec, ts, T, [0, 1], cs, flat, Xd, g2)
     assert torch.allclose(t_sums, s_res, rtol=1e-6) and torch.allclose(c_sums, s_mse, rtol=1e-6)
     assert rel_l2(g2.cpu(), g1.cpu()) < 2e-6
+
+
+@pytest.mark.parametrize("shape", [
+    # (d_in, d_out, hidden layers, width, grad cols): unusual I/O widths, one differentiated input
+    # (K1 = 2), a single hidden layer, a non-multiple-of-16 wide net
+    (7, 13, 2, 24, (3,)),
+    (16, 16, 1, 64, (0, 5, 15)),
+    (1, 1, 3, 8, (0,)),
+    (4, 9, 2, 100, (2, 3, 0)),
+])
+def test_forward_and_jet_odd_shapes_all_engines(shape):
+    d_in, d_out, L, W, gc = shape
+    g = torch.Generator().manual_seed(d_in * 100 + d_out)
+    desc = NetDesc(d_in, d_out, L, W, gc)
+    params = O.init_params(desc.layers, "xavier", g)
+    X = torch.rand(211, d_in, generator=g) * 2 - 1
+    Yo, dYo = O.jet([p.double() for p in params], X.double(), gc)
+    flat, Xd = O.flatten(params).cuda(), X.cuda()
+    for engine in (0, ENGINE_GENERIC):          # AUTO (fused / wide where supported) and the generic engine
+        eng = Engine(desc.with_(engine=engine))
+        Y, dY = eng.forward_jet(flat, Xd)
+        assert (Y.cpu().double() - Yo).abs().max() < 3e-6
+        assert (dY.cpu().double() - dYo).abs().max() < 3e-6 * max(1.0, float(dYo.abs().max()))
+        assert (eng.forward(flat, Xd).cpu().double() - Yo).abs().max() < 3e-6
+        # VJP of the jet (generic consumer path) against autograd
+        gY = torch.randn(211, d_out, generator=g)
+        gdY = torch.randn(len(gc), 211, d_out, generator=g)
+        p64 = [q.double().requires_grad_(True) for q in params]
+        cols = O.split_columns(X.double(), gc)
+        Yt = O.mlp_forward(p64, torch.cat(cols, -1))
+        dYt = torch.stack([torch.cat([O.compute_gradient(Yt[:, c:c + 1], cols[j]) for c in range(d_out)], 1) for j in gc])
+        go = O.flat_grad((Yt * gY.double()).sum() + (dYt * gdY.double()).sum(), p64)
+        grad = torch.zeros(desc.n_params, device="cuda")
+        eng.jet_backward(flat, Xd, gY.cuda(), gdY.cuda(), grad)
+        assert rel_l2(grad.cpu(), go) < 3e-5
