@@ -1,7 +1,8 @@
 // pinn_fused.hip — host side of the fused MFMA engine: weight packing, workspace carve,
 // launch geometry, cross-workgroup reductions.  Kernel: fused_kernel.h.
 #include <type_traits>
-#include "fused_kernel.h"
+#include <stdlib.h>
+#include "fused_pair_kernel.h"
 
 namespace pinn {
 
@@ -38,10 +39,30 @@ constexpr int64_t LDS_LIMIT = 160 * 1024;
 #ifndef PINN_NREP
 #define PINN_NREP 16
 #endif
-constexpr int NREP = PINN_NREP;   // replicated global accumulators when the gradient does not fit LDS
+constexpr int NREP = PINN_NREP;
+#ifndef PINN_FUSED_PAIR_DEFAULT
+#define PINN_FUSED_PAIR_DEFAULT 0
+#endif   // replicated global accumulators when the gradient does not fit LDS
 
 int64_t lds_fixed_bytes() { return (int64_t)(MAX_LOCKS + FUSED_WAVES * TB_PER_WAVE * TB_FLOATS + FUSED_WAVES * MAX_SUMS) * 4; }
 bool fits_lds(const Geo& g) { return (int64_t)g.PP * 4 + lds_fixed_bytes() <= LDS_LIMIT; }
+
+// two-waves-per-SIMD variant (fused_pair_kernel.h): width 64, even jets; PINN_FUSED_PAIR=0/1 overrides
+int64_t pair_lds_fixed_bytes() { return (int64_t)(MAX_LOCKS + PR_WAVES * PR_TB_PER_WAVE * TB_FLOATS + PR_WAVES * MAX_SUMS) * 4; }
+bool pair_default() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PINN_FUSED_PAIR");
+    v = e ? (atoi(e) != 0) : PINN_FUSED_PAIR_DEFAULT;
+  }
+  return v != 0;
+}
+bool use_pair(const Net& n, const Geo& g, bool grad) {
+  if (g.WP != 64 || (n.K1 != 2 && n.K1 != 4)) return false;
+  if (grad && (int64_t)g.PP * 4 + pair_lds_fixed_bytes() > LDS_LIMIT) return false;
+  if (grad && n.K1 == 2) return true;   // k_fused has no K1 = 2 gradient kernel
+  return pair_default();
+}
 
 int grid_for(int64_t n_tiles, bool one_per_cu) {
   int64_t want = (n_tiles + FUSED_WAVES - 1) / FUSED_WAVES;
@@ -194,11 +215,22 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
       for (int j = 0; j < PINN_MAX_ROLES; ++j) P.mse_col[j] = j < rq->n_cols ? rq->out_col[j] : -1;
     }
   }
-  const size_t lds = (size_t)P.lds_acc_floats * 4 + (size_t)lds_fixed_bytes();
+  const bool pair = use_pair(n, g, grad);
+  if (pair) {
+    P.n_tiles = (N + 7) / 8;
+    P.scratch_per_wave = (int64_t)n.L * (n.K1 / 2) * g.NTH * 256;
+    P.acc_lds = grad ? 1 : 0;
+    P.lds_acc_floats = grad ? g.PP : 0;
+  }
+  const size_t lds = (size_t)P.lds_acc_floats * 4 + (size_t)(pair ? pair_lds_fixed_bytes() : lds_fixed_bytes());
   // 8x64 gradient kernels fill the register file and most of LDS (1 workgroup per CU); the narrow
   // networks' kernels fit 2 waves per SIMD, which hides their per-layer latencies
   const bool one_per_cu = grad && P.acc_lds && !(g.WP <= 32 && 2 * (int64_t)lds <= LDS_LIMIT);
-  const int grid = grid_for(P.n_tiles, one_per_cu);
+  int grid = grid_for(P.n_tiles, one_per_cu);
+  if (pair) {   // one 8-wave workgroup per CU, 8 points per wave-tile
+    const int64_t want = (P.n_tiles + PR_WAVES - 1) / PR_WAVES;
+    grid = (int)(want < cu_count() ? (want < 1 ? 1 : want) : cu_count());
+  }
 
   const int packN = g.PW > g.PB ? g.PW : g.PB;
   hipLaunchKernelGGL(k_pack, dim3((packN + 255) / 256), dim3(256), 0, s, n, g.WP, params, (float*)(base + w.wp),
@@ -209,7 +241,8 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
     }
   }
   int rc;
-  switch (g.WP) {
+  if (pair) rc = launch_fused_pair(n.K1, grad, P, grid, lds, s);
+  else switch (g.WP) {
     case 16: rc = launch_fused<16>(n.K1, grad, P, grid, lds, s); break;
     case 32: rc = launch_fused<32>(n.K1, grad, P, grid, lds, s); break;
     default: rc = launch_fused<64>(n.K1, grad, P, grid, lds, s); break;
@@ -252,7 +285,9 @@ int fused_forward(const Net& n, const float* params, const float* X, int64_t N, 
 int fused_loss(const Net& n, const LossReq& rq, const float* params, const float* X, int64_t N, void* ws,
                int64_t ws_bytes, hipStream_t s) {
   const bool grad = rq.grad != nullptr;
-  if (grad && n.K1 == 2) { set_error("fused gradient kernels exist for K1 in {1,3,4}"); return PINN_ERR_UNSUPPORTED; }
+  if (grad && n.K1 == 2 && !use_pair(n, geo_of(n), true)) {
+    set_error("fused gradient kernels for K1 = 2 exist at hidden width 33..64 only"); return PINN_ERR_UNSUPPORTED;
+  }
   return run(n, grad, &rq, params, X, N, nullptr, nullptr, ws, ws_bytes, s);
 }
 
