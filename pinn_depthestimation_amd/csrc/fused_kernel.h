@@ -35,6 +35,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #ifndef PINN_FUSED_WAVES
 #define PINN_FUSED_WAVES 4
 #endif
+#ifndef PINN_FUSED_STREAM
+#define PINN_FUSED_STREAM 1   // streamed weights + copy-free layer loops (v6); 0 = the v5 prefetch structure
+#endif
 constexpr int FUSED_WAVES = PINN_FUSED_WAVES;
 constexpr int FUSED_THREADS = FUSED_WAVES * 64;
 constexpr int TB_FLOATS = 256;                // one 16x16 fp32 block, XOR-swizzled (see transpose_write)
@@ -102,6 +105,42 @@ __device__ __forceinline__ void gemm_chain(const f4 (&w)[NT_OUT][NT_IN], const f
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < K1; ++c) acc[c][MT] = mfma4(w[MT][kt][r], bin[c][kt][r], acc[c][MT]);
+}
+
+
+// One 16-row block of a layer's A operand: w[kt] = Wl[16MT + m][16kt + 4kq .. +3]  (row stride 16*NT_IN)
+template <int NT_IN>
+__device__ __forceinline__ void load_wblk(const float* __restrict__ Wl, int MT, f4 (&w)[NT_IN], int m, int kq) {
+#pragma unroll
+  for (int kt = 0; kt < NT_IN; ++kt)
+    w[kt] = *reinterpret_cast<const f4*>(Wl + (16 * MT + m) * (16 * NT_IN) + 16 * kt + 4 * kq);
+}
+
+// acc[c][MT] += W[16MT + m][:] . bin[c]  with the weights STREAMED one 16-row block ahead of the
+// MFMAs that use them: two blocks (8 f4 at width 64) are live instead of two whole layers, and
+// nothing but `wa` is carried from one GEMM to the next (no loop-carried register copies).  `wa`
+// holds block 0 on entry; while the last block computes, block 0 of the NEXT phase's matrix
+// (`Wnext`, same row stride) is fetched into `wa`: its latency hides behind this GEMM's tail and
+// the vector work between the two GEMMs.
+template <int NT_IN, int NT_OUT, int K1>
+__device__ __forceinline__ void gemm_stream(const float* __restrict__ Wl, const float* __restrict__ Wnext,
+                                            f4 (&wa)[NT_IN], const f4 (&bin)[K1][NT_IN], f4 (&acc)[K1][NT_OUT],
+                                            int m, int kq) {
+#pragma unroll
+  for (int MT = 0; MT < NT_OUT; ++MT) {
+    f4 wb[NT_IN];
+    if (MT + 1 < NT_OUT) load_wblk<NT_IN>(Wl, MT + 1, wb, m, kq);
+    else load_wblk<NT_IN>(Wnext, 0, wb, m, kq);
+#pragma unroll
+    for (int kt = 0; kt < NT_IN; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < K1; ++c) acc[c][MT] = mfma4(wa[kt][r], bin[c][kt][r], acc[c][MT]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kt = 0; kt < NT_IN; ++kt) wa[kt] = wb[kt];
+  }
 }
 
 template <int NT, int K1>
@@ -174,6 +213,47 @@ __device__ __forceinline__ void activate_adjoint(f4 (&G)[K1][NT], const f4 (&A)[
         const float s = a > 0.f ? 1.f : 0.01f;                   // piecewise linear: no second-derivative term
 #pragma unroll
         for (int c = 0; c < K1; ++c) G[c][MT][r] *= s;
+      }
+    }
+}
+
+
+// out-of-place forms: read the accumulators, write the next GEMM's B operand / the layer adjoint
+template <int ACT, int NT, int K1>
+__device__ __forceinline__ void activate_to(const f4 (&acc)[K1][NT], f4 (&a)[K1][NT]) {
+#pragma unroll
+  for (int MT = 0; MT < NT; ++MT)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float z = acc[0][MT][r];
+      float av, s;
+      if constexpr (ACT == PINN_ACT_TANH) { av = tanh_f32(z); s = fmaf(-av, av, 1.f); }
+      else { av = z > 0.f ? z : 0.01f * z; s = z > 0.f ? 1.f : 0.01f; }
+      a[0][MT][r] = av;
+#pragma unroll
+      for (int c = 1; c < K1; ++c) a[c][MT][r] = acc[c][MT][r] * s;
+    }
+}
+template <int ACT, int NT, int K1>
+__device__ __forceinline__ void activate_adjoint_to(const f4 (&G)[K1][NT], const f4 (&A)[K1][NT], f4 (&Z)[K1][NT]) {
+#pragma unroll
+  for (int MT = 0; MT < NT; ++MT)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float a = A[0][MT][r];
+      if constexpr (ACT == PINN_ACT_TANH) {
+        const float s = fmaf(-a, a, 1.f);
+        float cross = 0.f;
+#pragma unroll
+        for (int c = 1; c < K1; ++c) {
+          cross = fmaf(G[c][MT][r], A[c][MT][r], cross);
+          Z[c][MT][r] = G[c][MT][r] * s;
+        }
+        Z[0][MT][r] = fmaf(-2.f * a, cross, s * G[0][MT][r]);
+      } else {
+        const float s = a > 0.f ? 1.f : 0.01f;
+#pragma unroll
+        for (int c = 0; c < K1; ++c) Z[c][MT][r] = G[c][MT][r] * s;
       }
     }
 }
@@ -542,6 +622,83 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
     };
     f4 b0[K1][1];
     input_jet(b0);
+#if PINN_FUSED_STREAM
+    // ---- forward chain: weights streamed block-by-block (gemm_stream), activations written straight
+    // into the next GEMM's B operand: nothing is copied between layers ------------------------------
+    f4 a[K1][NTH];
+    f4 ws[NTH];   // the weight block the next GEMM starts with
+    {
+      f4 w0[NTH][1];
+      load_w<1, NTH>(Wp_, w0, p, q);
+      load_wblk<NTH>(Wp_ + w_off_p<WP>(L > 1 ? 1 : L), 0, ws, p, q);
+      f4 acc0[K1][NTH];
+      init_bias<NTH, K1>(Bp_ + b_off_p<WP>(0), acc0, q);
+      gemm_chain<1, NTH, K1>(w0, b0, acc0);
+      PINN_STAMP(0);
+      activate_to<ACT, NTH, K1>(acc0, a);
+    }
+    if (GRAD && L > 1) spill<NTH, K1>(scr, a, lane);      // a_L itself stays in registers for the reverse sweep
+    PINN_STAMP(1);
+    for (int l = 1; l < L; ++l) {
+      f4 nx[K1][NTH];
+      init_bias<NTH, K1>(Bp_ + b_off_p<WP>(l), nx, q);
+      gemm_stream<NTH, NTH, K1>(Wp_ + w_off_p<WP>(l), Wp_ + w_off_p<WP>(l + 1), ws, a, nx, p, q);
+      PINN_STAMP(0);
+      activate_to<ACT, NTH, K1>(nx, a);
+      if (GRAD && l < L - 1) spill<NTH, K1>(scr + l * SLOT, a, lane);   // (the last hidden jet is never re-read)
+      PINN_STAMP(1);
+    }
+    f4 out[K1][1];
+    init_bias<1, K1>(Bp_ + b_off_p<WP>(L), out, q);
+    // (the block fetched behind the output GEMM is W_{L-1}^T's first: the reverse sweep starts there)
+    gemm_stream<NTH, 1, K1>(Wp_ + w_off_p<WP>(L), WTp_ + w_off_p<WP>(L > 1 ? L - 1 : 0), ws, a, out, p, q);
+    // reverse-sweep operands whose latency the residual evaluation below hides
+    f4 wtl[NTH][1];
+    f4 ai[K1][NTH];
+    if constexpr (GRAD) {
+      load_w<1, NTH>(WTp_ + w_off_p<WP>(L), wtl, p, q);
+      unspill<NTH, K1>(scr + (L > 1 ? L - 2 : 0) * SLOT, ai, lane);            // a_{L-1}
+    }
+
+    // ---- outputs / loss -----------------------------------------------------------------------
+    f4 G[K1][1];
+    loss_epilogue<K1, GRAD>(P, out, G, sums, sm, sm_mse, tb, pt, ptc, valid, p, q);
+
+    PINN_STAMP(2);
+    // ---- reverse sweep ------------------------------------------------------------------------
+    // State entering iteration l: z = zbar of hidden layer l, ai = a_l (its load in flight), ws =
+    // first block of W_l^T.  The iteration runs  abar_l = W_l^T z  (a_l lands meanwhile), then
+    // dW_l = z (x) a_l, then z <- adjoint(abar_l, a_l) = zbar of layer l-1, and only then re-uses
+    // ai's registers for a_{l-1}: each spilled layer is read once, into the registers it is used
+    // from, and there are no loop-carried copies.
+    if constexpr (GRAD) {
+      weight_grad<1, NTH, K1>(sink, L, w_off_p<WP>(L), P.PW + b_off_p<WP>(L), G, a, tb, lane);
+      f4 z[K1][NTH];
+      {
+        f4 g[K1][NTH];
+        zero_tiles<NTH, K1>(g);
+        gemm_chain<1, NTH, K1>(wtl, G, g);
+        activate_adjoint_to<ACT, NTH, K1>(g, a, z);
+      }
+      for (int l = L - 1; l >= 1; --l) {
+        PINN_STAMP(3);
+        f4 g2[K1][NTH];
+        zero_tiles<NTH, K1>(g2);
+        gemm_stream<NTH, NTH, K1>(WTp_ + w_off_p<WP>(l), WTp_ + w_off_p<WP>(l >= 2 ? l - 1 : 1), ws, z, g2, p, q);
+        PINN_STAMP(6);
+        weight_grad<NTH, NTH, K1>(sink, l, w_off_p<WP>(l), P.PW + b_off_p<WP>(l), z, ai, tb, lane);
+        PINN_STAMP(5);
+        activate_adjoint_to<ACT, NTH, K1>(g2, ai, z);
+        if (l >= 2) unspill<NTH, K1>(scr + (l - 2) * SLOT, ai, lane);            // a_{l-1}
+        PINN_STAMP(4);
+      }
+      {  // layer 0: z = zbar_0, input = (x, unit tangents)
+        f4 b1[K1][1];
+        input_jet(b1);   // recomputed rather than kept live across the whole tile
+        weight_grad<NTH, 1, K1>(sink, 0, 0, P.PW + b_off_p<WP>(0), z, b1, tb, lane);
+      }
+    }
+#else
     // ---- forward chain (weights of layer l+1 are fetched while layer l computes) -------------
     f4 w0[NTH][1];
     load_w<1, NTH>(Wp_, w0, p, q);
@@ -626,6 +783,7 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
         weight_grad<NTH, 1, K1>(sink, 0, 0, P.PW + b_off_p<WP>(0), g, b1, tb, lane);
       }
     }
+#endif
     PINN_STAMP(7);
   }
 #ifdef PINN_DIAG

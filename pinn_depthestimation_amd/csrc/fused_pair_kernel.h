@@ -37,40 +37,6 @@ __device__ __forceinline__ float dpp_ror8(float v) {   // value of the lane 8 co
 }
 
 
-// One 16-row block of a layer's A operand: w[kt] = Wl[16MT + m][16kt + 4kq .. +3]  (row stride 16*NT_IN)
-template <int NT_IN>
-__device__ __forceinline__ void load_wblk(const float* __restrict__ Wl, int MT, f4 (&w)[NT_IN], int m, int kq) {
-#pragma unroll
-  for (int kt = 0; kt < NT_IN; ++kt)
-    w[kt] = *reinterpret_cast<const f4*>(Wl + (16 * MT + m) * (16 * NT_IN) + 16 * kt + 4 * kq);
-}
-
-// acc[i][MT] += W[16MT + m][:] . bin[i]  with the weights streamed one 16-row block ahead of the
-// MFMAs that use them (two blocks = 8 f4 live instead of a whole layer): `wa` holds block 0 on
-// entry; while the last block computes, block 0 of the NEXT phase's matrix (`Wnext`, same row
-// stride) is fetched into `wa`, so the load latency hides behind this GEMM's tail and the vector
-// work between the two GEMMs.
-template <int NT_IN, int NT_OUT, int NS>
-__device__ __forceinline__ void gemm_stream(const float* __restrict__ Wl, const float* __restrict__ Wnext,
-                                            f4 (&wa)[NT_IN], const f4 (&bin)[NS][NT_IN], f4 (&acc)[NS][NT_OUT],
-                                            int m, int kq) {
-#pragma unroll
-  for (int MT = 0; MT < NT_OUT; ++MT) {
-    f4 wb[NT_IN];
-    if (MT + 1 < NT_OUT) load_wblk<NT_IN>(Wl, MT + 1, wb, m, kq);
-    else load_wblk<NT_IN>(Wnext, 0, wb, m, kq);
-#pragma unroll
-    for (int kt = 0; kt < NT_IN; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int i = 0; i < NS; ++i) acc[i][MT] = mfma4(wa[kt][r], bin[i][kt][r], acc[i][MT]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kt = 0; kt < NT_IN; ++kt) wa[kt] = wb[kt];
-  }
-}
-
 template <int NT, int NS>
 __device__ __forceinline__ void init_bias_pr(const float* __restrict__ b, f4 (&acc)[NS][NT], int q, int j) {
 #pragma unroll
