@@ -35,6 +35,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #ifndef PINN_FUSED_WAVES
 #define PINN_FUSED_WAVES 4
 #endif
+#ifndef PINN_FUSED_BATCH_FLUSH
+#define PINN_FUSED_BATCH_FLUSH 4   // row blocks of the LDS gradient flush read per round trip (0 = one block at a time)
+#endif
 #ifndef PINN_FUSED_STREAM
 #define PINN_FUSED_STREAM 1   // streamed weights + copy-free layer loops (v6); 0 = the v5 prefetch structure
 #endif
@@ -219,13 +222,21 @@ __device__ __forceinline__ void activate_adjoint(f4 (&G)[K1][NT], const f4 (&A)[
 
 
 // out-of-place forms: read the accumulators, write the next GEMM's B operand / the layer adjoint
+// The bias is added here rather than used as the accumulators' initial value: its load is issued
+// before the GEMM and consumed after it (as an initial value its L2 latency sat exposed in front of
+// every layer's first MFMA), and every accumulator chain starts from the inline constant 0.
+template <int NT>
+__device__ __forceinline__ void load_bias(const float* __restrict__ b, f4 (&bias)[NT], int q) {
+#pragma unroll
+  for (int MT = 0; MT < NT; ++MT) bias[MT] = *reinterpret_cast<const f4*>(b + 16 * MT + 4 * q);
+}
 template <int ACT, int NT, int K1>
-__device__ __forceinline__ void activate_to(const f4 (&acc)[K1][NT], f4 (&a)[K1][NT]) {
+__device__ __forceinline__ void activate_to(const f4 (&acc)[K1][NT], const f4 (&bias)[NT], f4 (&a)[K1][NT]) {
 #pragma unroll
   for (int MT = 0; MT < NT; ++MT)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float z = acc[0][MT][r];
+      const float z = acc[0][MT][r] + bias[MT][r];
       float av, s;
       if constexpr (ACT == PINN_ACT_TANH) { av = tanh_f32(z); s = fmaf(-av, av, 1.f); }
       else { av = z > 0.f ? z : 0.01f * z; s = z > 0.f ? 1.f : 0.01f; }
@@ -305,6 +316,7 @@ constexpr int MAX_LOCKS = 128;
 // dW[16MT + 4(lane>>4) + r][16NT + (lane&15)]  at  woff + ((MT*NT_N + NT)*64 + lane)*4 + r.
 template <bool LDSACC>
 struct GradSink {
+  static constexpr bool LDS = LDSACC;
   float* acc;
   int* locks;
   __device__ __forceinline__ void lock(int l, int lane) const {
@@ -393,10 +405,31 @@ __device__ __forceinline__ void weight_grad(const Sink& sink, int layer, int wof
         for (int NT = 0; NT < NT_N; ++NT) dw[MT][NT] = mfma4(zt[c & 1][MT][s], at[c & 1][NT][s], dw[MT][NT]);
   }
   sink.lock(layer, lane);
+  if constexpr (Sink::LDS && PINN_FUSED_BATCH_FLUSH) {
+    // one LDS round trip per FLUSH_ROWS row blocks (all reads issued, then adds + writes) instead of
+    // one per 16x16 block: with a single wave per SIMD the serialized read-add-write chain is exposed
+    constexpr int FR = PINN_FUSED_BATCH_FLUSH < MT_N ? PINN_FUSED_BATCH_FLUSH : MT_N;
 #pragma unroll
-  for (int MT = 0; MT < MT_N; ++MT)
+    for (int M0 = 0; M0 < MT_N; M0 += FR) {
+      f4 cur[FR][NT_N];
 #pragma unroll
-    for (int NT = 0; NT < NT_N; ++NT) sink.add4(woff + ((MT * NT_N + NT) * 64 + lane) * 4, dw[MT][NT]);
+      for (int MT = M0; MT < M0 + FR && MT < MT_N; ++MT)
+#pragma unroll
+        for (int NT = 0; NT < NT_N; ++NT)
+          cur[MT - M0][NT] = *reinterpret_cast<const f4*>(sink.acc + woff + ((MT * NT_N + NT) * 64 + lane) * 4);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int MT = M0; MT < M0 + FR && MT < MT_N; ++MT)
+#pragma unroll
+        for (int NT = 0; NT < NT_N; ++NT)
+          *reinterpret_cast<f4*>(sink.acc + woff + ((MT * NT_N + NT) * 64 + lane) * 4) = cur[MT - M0][NT] + dw[MT][NT];
+    }
+  } else {
+#pragma unroll
+    for (int MT = 0; MT < MT_N; ++MT)
+#pragma unroll
+      for (int NT = 0; NT < NT_N; ++NT) sink.add4(woff + ((MT * NT_N + NT) * 64 + lane) * 4, dw[MT][NT]);
+  }
   if (q == 0) {
 #pragma unroll
     for (int MT = 0; MT < MT_N; ++MT) sink.add1(boff + 16 * MT + p, bs[MT]);
@@ -631,27 +664,36 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
       f4 w0[NTH][1];
       load_w<1, NTH>(Wp_, w0, p, q);
       load_wblk<NTH>(Wp_ + w_off_p<WP>(L > 1 ? 1 : L), 0, ws, p, q);
+      f4 bias[NTH];
+      load_bias<NTH>(Bp_ + b_off_p<WP>(0), bias, q);
       f4 acc0[K1][NTH];
-      init_bias<NTH, K1>(Bp_ + b_off_p<WP>(0), acc0, q);
+      zero_tiles<NTH, K1>(acc0);
       gemm_chain<1, NTH, K1>(w0, b0, acc0);
       PINN_STAMP(0);
-      activate_to<ACT, NTH, K1>(acc0, a);
+      activate_to<ACT, NTH, K1>(acc0, bias, a);
     }
     if (GRAD && L > 1) spill<NTH, K1>(scr, a, lane);      // a_L itself stays in registers for the reverse sweep
     PINN_STAMP(1);
     for (int l = 1; l < L; ++l) {
+      f4 bias[NTH];
+      load_bias<NTH>(Bp_ + b_off_p<WP>(l), bias, q);
       f4 nx[K1][NTH];
-      init_bias<NTH, K1>(Bp_ + b_off_p<WP>(l), nx, q);
+      zero_tiles<NTH, K1>(nx);
       gemm_stream<NTH, NTH, K1>(Wp_ + w_off_p<WP>(l), Wp_ + w_off_p<WP>(l + 1), ws, a, nx, p, q);
       PINN_STAMP(0);
-      activate_to<ACT, NTH, K1>(nx, a);
+      activate_to<ACT, NTH, K1>(nx, bias, a);
       if (GRAD && l < L - 1) spill<NTH, K1>(scr + l * SLOT, a, lane);   // (the last hidden jet is never re-read)
       PINN_STAMP(1);
     }
     f4 out[K1][1];
-    init_bias<1, K1>(Bp_ + b_off_p<WP>(L), out, q);
-    // (the block fetched behind the output GEMM is W_{L-1}^T's first: the reverse sweep starts there)
-    gemm_stream<NTH, 1, K1>(Wp_ + w_off_p<WP>(L), WTp_ + w_off_p<WP>(L > 1 ? L - 1 : 0), ws, a, out, p, q);
+    {
+      f4 bias_o[1];
+      load_bias<1>(Bp_ + b_off_p<WP>(L), bias_o, q);
+      zero_tiles<1, K1>(out);
+      // (the block fetched behind the output GEMM is W_{L-1}^T's first: the reverse sweep starts there)
+      gemm_stream<NTH, 1, K1>(Wp_ + w_off_p<WP>(L), WTp_ + w_off_p<WP>(L > 1 ? L - 1 : 0), ws, a, out, p, q);
+      out[0][0] += bias_o[0];
+    }
     // reverse-sweep operands whose latency the residual evaluation below hides
     f4 wtl[NTH][1];
     f4 ai[K1][NTH];
