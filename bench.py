@@ -178,7 +178,7 @@ def main():
         kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
         traffic = None   # HBM bytes per launch from the committed PMC passes of this same command
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "fused_v5_pmc_summary.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "fused_v6_pmc_summary.json")))
             if args.engine in (0, 2) and args.workload == "ns8x64":
                 traffic = pm["hbm_bytes_per_point"] * N
         except Exception:
@@ -197,7 +197,7 @@ def main():
                        "parallelism": f"dp{world}", "engine": args.engine, "final_loss": loss},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/r01/fused_v5_pmc_summary.json",
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/r01/fused_v6_pmc_summary.json",
                          "kernel": "pinn_residual_loss_grad (fwd jet + residual + reverse sweep)",
                          "kernel_ms": kern_ms, "flop_per_point": flop_pt},
         }
