@@ -490,7 +490,8 @@ __device__ __forceinline__ void scatter_adjoint(float* __restrict__ tb, const fl
 template <class RES, int K1, bool GRAD>
 __device__ __forceinline__ void residual_tile(const FusedParams& P, const f4 (&out)[K1][1], f4 (&G)[K1][1],
                                               float (&sums)[MAX_SUMS], const ScatterMap<K1>& sm,
-                                              float* __restrict__ tb, bool valid, bool masked, int p, int q) {
+                                              float* __restrict__ tb, bool valid, bool masked, int p, int q,
+                                              bool primary = true) {
   constexpr int NR = RES::NR, ND = RES::ND, NT = RES::NT;
   float v[1 + ND][NR], g[1 + ND][NR], sq[NT], sc[NT];
 #pragma unroll
@@ -505,7 +506,7 @@ __device__ __forceinline__ void residual_tile(const FusedParams& P, const f4 (&o
     RES::template eval<GRAD>(v, sc, g, sq, P.residual_id == PINN_RES_CONTINUITY_ONLY, masked, P.anchor);
   else
     RES::template eval<GRAD>(v, sc, g, sq);
-  if (valid && q == 0) {
+  if (valid && q == 0 && primary) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) sums[t] += sq[t];
   }
@@ -540,8 +541,9 @@ template <int K1, bool GRAD>
 __device__ __forceinline__ void loss_epilogue(const FusedParams& P, const f4 (&out)[K1][1], f4 (&G)[K1][1],
                                               float (&sums)[MAX_SUMS], const ScatterMap<K1>& sm,
                                               const ScatterMap<K1>& sm_mse, float* __restrict__ tb, int64_t pt,
-                                              int64_t ptc, bool valid, int p, int q) {
-  if (P.Y != nullptr && valid) {
+                                              int64_t ptc, bool valid, int p, int q, bool primary = true) {
+  // primary == false (cooperative kernel, waves 1..3): compute the output adjoint only — no stores, no sums
+  if (P.Y != nullptr && valid && primary) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int o = 4 * q + r;
@@ -558,13 +560,13 @@ __device__ __forceinline__ void loss_epilogue(const FusedParams& P, const f4 (&o
   for (int c = 0; c < K1; ++c) G[c][0] = f4{0.f, 0.f, 0.f, 0.f};
   if (P.loss_kind & 1) {
     if (P.residual_id == PINN_RES_NAVIER_STOKES) {
-      if constexpr (K1 >= 4) residual_tile<ResNavierStokes, K1, GRAD>(P, out, G, sums, sm, tb, valid, false, p, q);
+      if constexpr (K1 >= 4) residual_tile<ResNavierStokes, K1, GRAD>(P, out, G, sums, sm, tb, valid, false, p, q, primary);
     } else if (P.residual_id == PINN_RES_PHYSICS_EQUATION) {
-      if constexpr (K1 >= 3) residual_tile<ResPhysicsEquation, K1, GRAD>(P, out, G, sums, sm, tb, valid, false, p, q);
+      if constexpr (K1 >= 3) residual_tile<ResPhysicsEquation, K1, GRAD>(P, out, G, sums, sm, tb, valid, false, p, q, primary);
     } else {
       if constexpr (K1 >= 3) {
         const bool masked = P.residual_id == PINN_RES_CONTINUITY_ONLY && P.X[ptc * P.d_in + P.xcol] < P.thr;
-        residual_tile<ResContinuity, K1, GRAD>(P, out, G, sums, sm, tb, valid, masked, p, q);
+        residual_tile<ResContinuity, K1, GRAD>(P, out, G, sums, sm, tb, valid, masked, p, q, primary);
       }
     }
   }
@@ -576,7 +578,7 @@ __device__ __forceinline__ void loss_epilogue(const FusedParams& P, const f4 (&o
       if (j < P.n_cols) {
         const float y = gather_out(out[0][0], P.mse_col[j], p);
         const float d = P.T[ptc * P.n_cols + j] - y;                  // train.py:141 (true - pred)
-        if (valid && q == 0) sums[MSE_SUM0 + j] += d * d;
+        if (valid && q == 0 && primary) sums[MSE_SUM0 + j] += d * d;
         if (GRAD) gm[0][j] = -2.f * P.mse_scale[j] * d;
       }
     }

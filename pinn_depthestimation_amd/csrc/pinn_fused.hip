@@ -3,6 +3,7 @@
 #include <type_traits>
 #include <stdlib.h>
 #include "fused_pair_kernel.h"
+#include "fused_coop_kernel.h"
 
 namespace pinn {
 
@@ -49,19 +50,32 @@ bool fits_lds(const Geo& g) { return (int64_t)g.PP * 4 + lds_fixed_bytes() <= LD
 
 // two-waves-per-SIMD variant (fused_pair_kernel.h): width 64, even jets; PINN_FUSED_PAIR=0/1 overrides
 int64_t pair_lds_fixed_bytes() { return (int64_t)(MAX_LOCKS + PR_WAVES * PR_TB_PER_WAVE * TB_FLOATS + PR_WAVES * MAX_SUMS) * 4; }
-bool pair_default() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("PINN_FUSED_PAIR");
-    v = e ? (atoi(e) != 0) : PINN_FUSED_PAIR_DEFAULT;
-  }
-  return v != 0;
+bool pair_default() {   // read per call (the tests flip it)
+  const char* e = getenv("PINN_FUSED_PAIR");
+  return e ? (atoi(e) != 0) : (PINN_FUSED_PAIR_DEFAULT != 0);
 }
 bool use_pair(const Net& n, const Geo& g, bool grad) {
   if (g.WP != 64 || (n.K1 != 2 && n.K1 != 4)) return false;
   if (grad && (int64_t)g.PP * 4 + pair_lds_fixed_bytes() > LDS_LIMIT) return false;
   if (grad && n.K1 == 2) return true;   // k_fused has no K1 = 2 gradient kernel
   return pair_default();
+}
+
+// cooperative (four waves per tile) kernel for small point sets (fused_coop_kernel.h): one workgroup
+// per CU runs a tile in ~45 us against ~110 us for k_fused's one-wave tile, so it wins while there is
+// at most one tile per CU (measured: loss+grad 127 -> 69 us at N = 243, 137 -> 93 us at N = 4096,
+// break-even at N = 8192).  PINN_FUSED_COOP=0/1 overrides.
+int64_t coop_lds_bytes(const Net& n, const Geo& g, bool grad) {
+  return ((int64_t)(grad ? g.PP : 0) + 2 * (int64_t)n.K1 * 4 * TB_FLOATS + MAX_SUMS) * 4;
+}
+bool use_coop(const Net& n, const Geo& g, bool grad, int64_t N) {
+  const char* e = getenv("PINN_FUSED_COOP");   // read per call: the tests flip it to cover both kernels
+  const int forced = e ? (atoi(e) != 0) : -1;
+  if (forced == 0 || g.WP != 64) return false;
+  if (grad ? (n.K1 == 2) : false) return false;
+  if (coop_lds_bytes(n, g, grad) > LDS_LIMIT) return false;
+  if (forced == 1) return true;
+  return (N + 15) / 16 <= (int64_t)cu_count();
 }
 
 int grid_for(int64_t n_tiles, bool one_per_cu) {
@@ -81,6 +95,11 @@ WsLayout ws_layout(const Net& n, const Geo& g, int64_t N) {
   WsLayout w;
   const int64_t n_tiles = (N + 15) / 16;
   w.max_grid = grid_for(n_tiles, false);
+  {   // the cooperative kernel launches one workgroup per tile (up to 2 per CU)
+    const int64_t cap = 2 * (int64_t)cu_count();
+    const int64_t coop_grid = n_tiles < cap ? n_tiles : cap;
+    if (coop_grid > w.max_grid) w.max_grid = (int)coop_grid;
+  }
   int64_t off = 0;
   w.wp = off; off += al((int64_t)g.PW * 4);
   w.wtp = off; off += al((int64_t)g.PW * 4);
@@ -215,18 +234,28 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
       for (int j = 0; j < PINN_MAX_ROLES; ++j) P.mse_col[j] = j < rq->n_cols ? rq->out_col[j] : -1;
     }
   }
-  const bool pair = use_pair(n, g, grad);
+  const bool coop = use_coop(n, g, grad, N);
+  const bool pair = !coop && use_pair(n, g, grad);
+  if (coop) {
+    P.acc_lds = grad ? 1 : 0;
+    P.lds_acc_floats = grad ? g.PP : 0;
+  }
   if (pair) {
     P.n_tiles = (N + 7) / 8;
     P.scratch_per_wave = (int64_t)n.L * (n.K1 / 2) * g.NTH * 256;
     P.acc_lds = grad ? 1 : 0;
     P.lds_acc_floats = grad ? g.PP : 0;
   }
-  const size_t lds = (size_t)P.lds_acc_floats * 4 + (size_t)(pair ? pair_lds_fixed_bytes() : lds_fixed_bytes());
+  const size_t lds = coop ? (size_t)coop_lds_bytes(n, g, grad)
+                          : (size_t)P.lds_acc_floats * 4 + (size_t)(pair ? pair_lds_fixed_bytes() : lds_fixed_bytes());
   // 8x64 gradient kernels fill the register file and most of LDS (1 workgroup per CU); the narrow
   // networks' kernels fit 2 waves per SIMD, which hides their per-layer latencies
   const bool one_per_cu = grad && P.acc_lds && !(g.WP <= 32 && 2 * (int64_t)lds <= LDS_LIMIT);
   int grid = grid_for(P.n_tiles, one_per_cu);
+  if (coop) {   // one workgroup per tile, at most one per CU (gradient kernels fill the LDS)
+    const int64_t cap = (int64_t)cu_count() * (grad ? 1 : 2);
+    grid = (int)(P.n_tiles < cap ? (P.n_tiles < 1 ? 1 : P.n_tiles) : cap);
+  }
   if (pair) {   // one 8-wave workgroup per CU, 8 points per wave-tile
     const int64_t want = (P.n_tiles + PR_WAVES - 1) / PR_WAVES;
     grid = (int)(want < cu_count() ? (want < 1 ? 1 : want) : cu_count());
@@ -241,7 +270,8 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
     }
   }
   int rc;
-  if (pair) rc = launch_fused_pair(n.K1, grad, P, grid, lds, s);
+  if (coop) rc = launch_fused_coop(n.K1, grad, P, grid, lds, s);
+  else if (pair) rc = launch_fused_pair(n.K1, grad, P, grid, lds, s);
   else switch (g.WP) {
     case 16: rc = launch_fused<16>(n.K1, grad, P, grid, lds, s); break;
     case 32: rc = launch_fused<32>(n.K1, grad, P, grid, lds, s); break;

@@ -1,0 +1,44 @@
+// pinn_fused_coop.hip — instantiations of the cooperative (four waves per tile) fused kernel for
+// small point sets (fused_coop_kernel.h); hidden width padded to 64
+#include <type_traits>
+#include "fused_coop_kernel.h"
+
+namespace pinn {
+
+template <int K1, bool GRAD, int ACT>
+static int launch_coop_act(const FusedParams& P, int grid, size_t lds, hipStream_t s) {
+  auto kern = k_fused_coop<K1, GRAD, ACT>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e)); return PINN_ERR_LAUNCH; }
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(COOP_THREADS), lds, s, P);
+  return check_launch("fused cooperative kernel");
+}
+
+template <int K1, bool GRAD>
+static int launch_coop(const FusedParams& P, int grid, size_t lds, hipStream_t s) {
+  return P.act == PINN_ACT_TANH ? launch_coop_act<K1, GRAD, PINN_ACT_TANH>(P, grid, lds, s)
+                                : launch_coop_act<K1, GRAD, PINN_ACT_LEAKY_RELU>(P, grid, lds, s);
+}
+
+int launch_fused_coop(int K1, bool grad, const FusedParams& P, int grid, size_t lds, hipStream_t s) {
+  if (!grad) {
+    switch (K1) {
+      case 1: return launch_coop<1, false>(P, grid, lds, s);
+      case 2: return launch_coop<2, false>(P, grid, lds, s);
+      case 3: return launch_coop<3, false>(P, grid, lds, s);
+      case 4: return launch_coop<4, false>(P, grid, lds, s);
+    }
+  } else {
+    switch (K1) {
+      case 1: return launch_coop<1, true>(P, grid, lds, s);
+      case 3: return launch_coop<3, true>(P, grid, lds, s);
+      case 4: return launch_coop<4, true>(P, grid, lds, s);
+    }
+  }
+  set_error("fused cooperative engine: no kernel for K1=%d grad=%d", K1, (int)grad);
+  return PINN_ERR_UNSUPPORTED;
+}
+
+}  // namespace pinn

@@ -52,6 +52,17 @@ def rel_l2(a, b):
 ENGINES = [ENGINE_GENERIC, ENGINE_FUSED]
 
 
+@pytest.fixture(autouse=True, params=["tile", "coop", "pair"])
+def fused_kernel_choice(request, monkeypatch):
+    """The fused engine has three kernels at padded width 64: one wave per 16-point tile (k_fused), four
+    waves per tile (k_fused_coop, picked automatically for small N) and the opt-in two-waves-per-SIMD
+    8-point layout (k_fused_pair, even jets).  Every test in this module runs with each forced in turn
+    (the library reads PINN_FUSED_COOP / PINN_FUSED_PAIR per call; other shapes ignore them)."""
+    monkeypatch.setenv("PINN_FUSED_COOP", "1" if request.param == "coop" else "0")
+    monkeypatch.setenv("PINN_FUSED_PAIR", "1" if request.param == "pair" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("name", ["ns_8x64", "ns_5in", "pe_10x10", "cf_4x20"])
 def test_forward_and_jet(name, engine):
@@ -200,6 +211,7 @@ def test_residual_and_mse_in_one_pass(engine):
 
 
 @pytest.mark.parametrize("shape", [
+    (3, 5, 3, 48, (1,)),          # k = 1 jet at padded width 64
     # (d_in, d_out, hidden layers, width, grad cols): unusual I/O widths, one differentiated input
     # (K1 = 2), a single hidden layer, a non-multiple-of-16 wide net
     (7, 13, 2, 24, (3,)),

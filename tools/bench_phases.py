@@ -18,7 +18,7 @@ grad = torch.zeros(desc.n_params, device="cuda")
 T = torch.rand(N, 4, generator=g).cuda()
 cs = torch.full((4,), 1.0 / N, device="cuda")
 
-def timeit(name, fn, flop_per_pt, reps=5):
+def timeit(name, fn, flop_per_pt, reps=int(os.environ.get("REPS", "5"))):
     fn(); torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
