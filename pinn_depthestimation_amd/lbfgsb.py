@@ -39,4 +39,5 @@ class LBFGSBOptimizer:
         x0 = self.trainer.dnn.flat_params().detach().to("cpu", torch.float64).numpy()
         res = minimize(self.function_for_scipy, x0, jac=True, method="L-BFGS-B", options=self.options)
         self.function_for_scipy(res.x)      # leave the best point in the network
+        self.trainer.flush_log()
         return res

@@ -7,8 +7,10 @@ One closure evaluation =
     fidelity   : pinn_mse_loss_grad       (train.py:131-141)
     residual   : pinn_residual_loss_grad  (train.py:144-154 + loss.backward(), :191)
     all-reduce : [grad | loss sums] over the data-parallel group (parallel.py)
-No host synchronisation happens unless a log line is due (`log_every`; the reference logs
-every call, train.py:160-173 — pass log_every=1 for that).
+The reference logs every call (train.py:160-173), i.e. one host synchronisation per iteration.
+Here the three loss values of a logged iteration are copied into a device-side ring and written
+out `log_flush_every` entries at a time (one synchronisation per flush; `log_flush_every=1`
+restores line-by-line behaviour): log.txt has the same lines, just written in batches.
 """
 from __future__ import annotations
 
@@ -70,7 +72,8 @@ class PINN:
                  device="cuda", log_dir: Optional[str] = None, log_every: int = 1, checkpoint_every: int = 1000,
                  reducer: Optional[Reducer] = None, evaluator: Optional[Callable] = None,
                  dnn: Optional[DNN] = None, engine: int = 0, mat_dump_iter: Optional[int] = None,
-                 mat_dump_path: str = "data_at50k.mat", residual_batch: Optional[int] = None, seed: int = 1234):
+                 mat_dump_path: str = "data_at50k.mat", residual_batch: Optional[int] = None, seed: int = 1234,
+                 log_flush_every: int = 100):
         cfg = config if isinstance(config, PinnConfig) else load_config(config)
         self.config, self.device = cfg, torch.device(device)
         self.reducer = reducer or Reducer()
@@ -114,6 +117,7 @@ class PINN:
         self._fid_scale = (self.weight_fidelity * self._fid_unit).contiguous()
         self._res_scale = (self.weight_residual * self._res_unit).contiguous()
         self.buf = torch.zeros(P + nf + nt, dtype=torch.float32, device=dev)   # ONE all-reduce per closure
+        self._loss_mat = None      # (3, nf + nt): [fidelity, residual, total] = _loss_mat @ [fid sums | res sums]
         self.grad = self.buf[:P]
         self._fid_sums, self._res_sums = self.buf[P:P + nf], self.buf[P + nf:]
         self.evaluator = evaluator or HipEvaluator(cfg.layers, cfg.init_type, cfg.grad_cols, self.spec,
@@ -134,7 +138,9 @@ class PINN:
         self.adam_maxit = cfg.adam["max_it"]
         self.log_dir, self.log_every, self.checkpoint_every = log_dir, max(int(log_every), 1), checkpoint_every
         self._log_fh = None
-        self.history: List[tuple] = []
+        self._history: List[tuple] = []
+        self._ring = torch.zeros(max(int(log_flush_every), 1), 3, dtype=torch.float32, device=dev)
+        self._ring_iters: List[int] = []
         self.last = None
         self.init_optimizers()
 
@@ -170,13 +176,24 @@ class PINN:
         self.evaluator(self.theta, self.Xf, self.Tf, self._fid_scale, Xr, self._res_scale, self.grad,
                        self._fid_sums, self._res_sums)
         self.reducer.allreduce_sum_(self.buf)
-        fidelity_loss = (self._fid_sums * self._fid_unit).sum()
-        residual_loss = (self._res_sums * self._res_unit).sum()
-        loss = self.weight_fidelity * fidelity_loss + self.weight_residual * residual_loss   # train.py:157
-        self.last = (fidelity_loss, residual_loss, loss)
+        if self._loss_mat is None:
+            nf = self._fid_sums.numel()
+            m = torch.zeros(3, self.buf.numel() - self.theta.numel(), dtype=torch.float32, device=self.device)
+            m[0, :nf] = self._fid_unit
+            m[1, nf:] = self._res_unit
+            m[2] = self.weight_fidelity * m[0] + self.weight_residual * m[1]                  # train.py:157
+            self._loss_mat = m
         self.iter += 1                                                                        # train.py:160
-        if self.iter % self.log_every == 0 or self.iter % 1000 == 0:
-            self._log(fidelity_loss.item(), residual_loss.item(), loss.item())
+        logged = self.iter % self.log_every == 0 or self.iter % 1000 == 0
+        # one small mat-vec gives the three losses; a logged iteration computes them straight into the ring
+        vec = torch.mv(self._loss_mat, self.buf[self.theta.numel():],
+                       out=self._ring[len(self._ring_iters)] if logged else None)
+        fidelity_loss, residual_loss, loss = vec[0], vec[1], vec[2]
+        self.last = (fidelity_loss, residual_loss, loss)
+        if logged:
+            self._ring_iters.append(self.iter)
+            if len(self._ring_iters) == self._ring.shape[0]:
+                self.flush_log()
         if self.checkpoint_every:
             every = self.checkpoint_every
             if self.config.variant == "newmethod" and self.checkpoint_every == 1000:
@@ -185,10 +202,32 @@ class PINN:
                 self.save_checkpoint(f"model_{self.iter}.pth")                                # train.py:175-179
         return loss
 
-    def _log(self, fid: float, res: float, tot: float):
-        self.history.append((self.iter, fid, res, tot))
-        if self.iter % 1000 == 0 and self.reducer.rank == 0:
-            print(f"Epoch {self.iter}, Fidelity Loss: {fid:.5e}, Residual Loss: {res:.5e}, Total Loss: {tot:.5e}")
+    @property
+    def history(self) -> List[tuple]:
+        """(iteration, fidelity, residual, total) of every logged iteration so far."""
+        self.flush_log()
+        return self._history
+
+    @history.setter
+    def history(self, value):
+        self._ring_iters = []
+        self._history = list(value)
+
+    def flush_log(self):
+        """Bring the pending ring entries to the host (ONE synchronisation) and write them out."""
+        if not self._ring_iters:
+            return
+        rows = self._ring[:len(self._ring_iters)].cpu().tolist()
+        iters, self._ring_iters = self._ring_iters, []
+        for it, (fid, res, tot) in zip(iters, rows):
+            self._log(it, fid, res, tot)
+        if self._log_fh is not None:
+            self._log_fh.flush()
+
+    def _log(self, it: int, fid: float, res: float, tot: float):
+        self._history.append((it, fid, res, tot))
+        if it % 1000 == 0 and self.reducer.rank == 0:
+            print(f"Epoch {it}, Fidelity Loss: {fid:.5e}, Residual Loss: {res:.5e}, Total Loss: {tot:.5e}")
         if self.log_dir is None or self.reducer.rank != 0:
             return
         if self._log_fh is None:
@@ -198,8 +237,7 @@ class PINN:
             self._log_fh = open(path, "a")
             if new:
                 self._log_fh.write("Epoch, Fidelity Loss, Residual Loss, Total Loss\n")       # train.py:167
-        self._log_fh.write(f"{self.iter}, {fid:.5e}, {res:.5e}, {tot:.5e}\n")                 # train.py:170
-        self._log_fh.flush()
+        self._log_fh.write(f"{it}, {fid:.5e}, {res:.5e}, {tot:.5e}\n")                        # train.py:170
 
     def dump_predictions(self, path: str):
         """savemat of pred_<key> (N,1) float32 for every network output on the (local) residual
@@ -212,6 +250,7 @@ class PINN:
             print(f"Data saved to {path} after {self.iter} iterations.")
 
     def save_checkpoint(self, name: str):
+        self.flush_log()
         if self.log_dir is None or self.reducer.rank != 0:
             return
         os.makedirs(self.log_dir, exist_ok=True)
@@ -240,8 +279,7 @@ class PINN:
             self.adam_step()
         if self.config.lbfgs["max_it"] > 0:
             self.optimizer_LBFGS.step(self.closure)                                # ONE step, train.py:200
-        if self._log_fh is not None:
-            self._log_fh.flush()
+        self.flush_log()
 
     def predict(self, inputs) -> torch.Tensor:
         """Forward on a grid (test.py:76): (N, d_in) -> (N, d_out)."""

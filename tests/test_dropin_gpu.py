@@ -139,6 +139,7 @@ def test_g6_trainer_loss_func_config_cmb(tmp_path):
     assert abs(res - float(z["res"])) / float(z["res"]) < 2e-5
     assert abs(loss.item() - float(z["loss"])) / float(z["loss"]) < 2e-5
     assert rel_l2(tr.grad.cpu(), z["grad"]) < 1e-4
+    tr.flush_log()          # log lines are written in batches (trainer.py docstring)
     lines = open(tmp_path / "log.txt").read().splitlines()
     assert lines[0] == "Epoch, Fidelity Loss, Residual Loss, Total Loss"       # train.py:167
     assert lines[1] == f"1, {fid:.5e}, {res:.5e}, {tot:.5e}"
