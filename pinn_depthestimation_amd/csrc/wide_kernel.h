@@ -23,6 +23,9 @@ namespace pinn {
 constexpr int WIDE_WAVES = 4;
 constexpr int WIDE_THREADS = WIDE_WAVES * 64;
 constexpr int WIDE_MAX_PADS = 20;   // 4 zbar tiles + 16 input tiles of one quantity
+#ifndef PINN_WIDE_SHARE_A
+#define PINN_WIDE_SHARE_A 1
+#endif
 
 struct WideLayer {
   const float* W;        // this layer's padded weights, row-major [16*NTO][16*NTI] (fwd) or W^T (bwd)
@@ -284,6 +287,75 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_wgrad(const FusedParam
     for (int NT = 0; NT < NTN; ++NT) dw[MT][NT] = f4{0.f, 0.f, 0.f, 0.f};
   }
   const int gw = blockIdx.x * GPW + wave / RB, nw = gridDim.x * GPW;
+#if PINN_WIDE_SHARE_A
+  // W = 256 hidden layers (four row blocks = the four waves, all on the same tile): the 16 input tiles
+  // every wave needs are loaded and transposed ONCE per workgroup — each wave handles four of them
+  // into a shared, double-buffered set of pads, one barrier per (tile, quantity) — instead of once
+  // per wave.  That frees the registers the fp32 kernel lacked for fetching one step ahead (its
+  // in-place loads left the HBM latency exposed before every quantity: 40 % of the MFMA rate).
+  if constexpr (RB == WIDE_WAVES && !FIRST && NTN % WIDE_WAVES == 0) {
+    constexpr int APW = NTN / WIDE_WAVES;
+    float* zpad = smem + wave * (4 * TB_FLOATS);
+    float* apad = smem + WIDE_WAVES * 4 * TB_FLOATS;          // 2 x NTN pads
+    f4 rz[MTB], ra[APW];
+    auto fetch = [&](int64_t t, int c) {
+#pragma unroll
+      for (int MT = 0; MT < MTB; ++MT)
+        rz[MT] = *reinterpret_cast<const f4*>(Lp.g_in + ((t * K1 + c) * NTM + rb * MTB + MT) * 256 + lane * 4);
+#pragma unroll
+      for (int i = 0; i < APW; ++i)
+        ra[i] = *reinterpret_cast<const f4*>(Lp.in_act + ((t * K1 + c) * NTN + wave * APW + i) * 256 + lane * 4);
+    };
+    if (gw < Lp.n_tiles) fetch(gw, 0);
+    int buf = 0;
+    for (int64_t t = gw; t < Lp.n_tiles; t += nw) {      // gw, nw are workgroup-uniform here (GPW == 1)
+#pragma unroll
+      for (int c = 0; c < K1; ++c) {
+        float* ap = apad + buf * (NTN * TB_FLOATS);
+#pragma unroll
+        for (int MT = 0; MT < MTB; ++MT) transpose_write(zpad + MT * TB_FLOATS, rz[MT], p, q);
+#pragma unroll
+        for (int i = 0; i < APW; ++i) transpose_write(ap + (wave * APW + i) * TB_FLOATS, ra[i], p, q);
+        if (c + 1 < K1) fetch(t, c + 1);
+        else if (t + nw < Lp.n_tiles) fetch(t + nw, 0);
+        __syncthreads();
+        f4 zt[MTB];
+#pragma unroll
+        for (int MT = 0; MT < MTB; ++MT) zt[MT] = transpose_read<BF16>(zpad + MT * TB_FLOATS, p, q);
+        if (c == 0) {
+#pragma unroll
+          for (int MT = 0; MT < MTB; ++MT) bs[MT] += (zt[MT][0] + zt[MT][1]) + (zt[MT][2] + zt[MT][3]);
+        }
+#pragma unroll
+        for (int N0 = 0; N0 < NTN; N0 += 4) {
+          f4 at[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) at[j] = transpose_read<BF16>(ap + (N0 + j) * TB_FLOATS, p, q);
+          if constexpr (BF16) {
+            bf16x4 a16[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a16[j] = to_bf16x4(at[j]);
+#pragma unroll
+            for (int MT = 0; MT < MTB; ++MT) {
+              const bf16x4 z16 = to_bf16x4(zt[MT]);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) dw[MT][N0 + j] = mfma_bf16(z16, a16[j], dw[MT][N0 + j]);
+            }
+          } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+              for (int MT = 0; MT < MTB; ++MT)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dw[MT][N0 + j] = mfma4(zt[MT][s], at[j][s], dw[MT][N0 + j]);
+          }
+        }
+        buf ^= 1;
+      }
+    }
+  } else
+#endif
+  {
   // raw (acc-layout) tiles of ONE quantity, fetched one step ahead of their use: with a single wave
   // per SIMD the HBM/L2 latency of these loads is otherwise fully exposed before every transpose.
   f4 rz[MTB], ra[NTN];
@@ -350,6 +422,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_wgrad(const FusedParam
             for (int NT = 0; NT < NTN; ++NT) dw[MT][NT] = mfma4(zt[MT][s], at[NT][s], dw[MT][NT]);
       }
     }
+  }
   }
   // one flush per wave into the flat torch-layout gradient (out_d x in_d row-major)
 #pragma unroll
