@@ -33,6 +33,7 @@ WORKLOADS = {
     "co100x20": (2, 3, 100, 20, (0, 1), "continuity_ftemp", ("x", "y"), ("U", "V", "h"), 6 * (2 * 20 + 99 * 400 + 60) * 3),  # config_CMB_h.json net
 }
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PEAK_BF16_MFMA_TFLOPS = 2516.8    # same guide: dense bf16 MFMA = 16x the fp32 matrix rate (~2.5 PF)
 PTS_PER_GPU = 1 << 20
 
 
@@ -184,6 +185,7 @@ def main():
         except Exception:
             pass
         achieved = N * flop_pt / (kern_ms * 1e-3) / 1e12
+        peak = PEAK_BF16_MFMA_TFLOPS if args.bf16 else PEAK_F32_MFMA_TFLOPS
         out = {
             "metric": "collocation-point residuals/sec (fwd+PDE-grad+Adam)",
             "value": n_global * args.steps / dt, "unit": "residual-points/s",
@@ -195,9 +197,10 @@ def main():
                                    f"{N} synthetic ({','.join(in_names)}) points per GPU, full-batch Adam step",
                        "points_per_gpu": N, "global_points": n_global, "params": P,
                        "parallelism": f"dp{world}", "engine": args.engine, "final_loss": loss},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/r01/fused_v6_pmc_summary.json",
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "traffic_source": ("rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, "
+                                            "profiles/r01/fused_v6_pmc_summary.json") if traffic is not None else None,
                          "kernel": "pinn_residual_loss_grad (fwd jet + residual + reverse sweep)",
                          "kernel_ms": kern_ms, "flop_per_point": flop_pt},
         }
