@@ -24,6 +24,7 @@ from ._lib import PinnError
 from .config import PinnConfig, load_config
 from .dnn import DNN
 from .engine import ACTIVATION_OF_INIT, Engine, NetDesc, ResidualSpec
+from .lbfgs import FlatLBFGS
 from .parallel import Reducer
 
 
@@ -73,7 +74,7 @@ class PINN:
                  reducer: Optional[Reducer] = None, evaluator: Optional[Callable] = None,
                  dnn: Optional[DNN] = None, engine: int = 0, mat_dump_iter: Optional[int] = None,
                  mat_dump_path: str = "data_at50k.mat", residual_batch: Optional[int] = None, seed: int = 1234,
-                 log_flush_every: int = 100):
+                 log_flush_every: int = 100, lbfgs_impl: str = "flat"):
         cfg = config if isinstance(config, PinnConfig) else load_config(config)
         self.config, self.device = cfg, torch.device(device)
         self.reducer = reducer or Reducer()
@@ -134,6 +135,7 @@ class PINN:
             self._res_unit = torch.full((nt,), 1.0 / (residual_batch * self.reducer.world), dtype=torch.float32, device=dev)
             self._res_scale = (self.weight_residual * self._res_unit).contiguous()
         self.mat_dump_iter, self.mat_dump_path = mat_dump_iter, mat_dump_path
+        self.lbfgs_impl = lbfgs_impl     # "flat": lbfgs.FlatLBFGS (batched recursion); "torch": torch.optim.LBFGS
         self.iter = 0                                                      # train.py:73
         self.adam_maxit = cfg.adam["max_it"]
         self.log_dir, self.log_every, self.checkpoint_every = log_dir, max(int(log_every), 1), checkpoint_every
@@ -152,7 +154,8 @@ class PINN:
         self._adam_step = 0
         self._sched_steps = 0
         self.theta_param = torch.nn.Parameter(self.theta)       # shares storage with every Linear weight
-        self.optimizer_LBFGS = torch.optim.LBFGS(
+        lbfgs_cls = FlatLBFGS if self.lbfgs_impl == "flat" else torch.optim.LBFGS
+        self.optimizer_LBFGS = lbfgs_cls(
             [self.theta_param], lr=lb["learning_rate"], max_iter=lb["max_it"], max_eval=lb.get("max_evaluation"),
             history_size=lb["history_size"], tolerance_grad=lb["tolerance_grad"],
             tolerance_change=lb["tolerance_change"], line_search_fn=lb["line_search_fn"])
