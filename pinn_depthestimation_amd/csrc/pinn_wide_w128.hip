@@ -29,13 +29,19 @@ template <int K1, bool BF>
 static int fwd_k(int which, bool grad, const FusedParams& P, const WideLayer& Lp, int grid, hipStream_t s) {
   constexpr int A = PINN_ACT_TANH;
   switch (which) {
-    case 0: return go(k_wide_fwd<1, NTW_, K1, A, true, false, false, false>, P, Lp, dim3(grid), 0, s, "wide fwd first");
+    case 0:   // (bf16 mode: jets are stored as bf16 — wide_kernel.h FMT bits — while the thin layers' MFMAs stay fp32)
+      if constexpr (BF) return go(k_wide_fwd<1, NTW_, K1, A, true, false, false, false, 1, FMT_OUT16>, P, Lp, dim3(grid), 0, s, "wide fwd first");
+      else return go(k_wide_fwd<1, NTW_, K1, A, true, false, false, false>, P, Lp, dim3(grid), 0, s, "wide fwd first");
     case 1:   // two waves per tile pay off only once bf16 has shortened the MFMA block (measured: fp32 -8 %, bf16 +11 %)
-      if constexpr (BF) return go2(k_wide_fwd<NTW_, NTW_, K1, A, false, false, false, true, 2>, P, Lp, dim3(grid), 0, s, "wide fwd hidden");
+      if constexpr (BF) return go2(k_wide_fwd<NTW_, NTW_, K1, A, false, false, false, true, 2, FMT_IN16 | FMT_OUT16>, P, Lp, dim3(grid), 0, s, "wide fwd hidden");
       else return go(k_wide_fwd<NTW_, NTW_, K1, A, false, false, false, false, 1>, P, Lp, dim3(grid), 0, s, "wide fwd hidden");
     default:
-      return grad ? go(k_wide_fwd<NTW_, 1, K1, A, false, true, true, false>, P, Lp, dim3(grid), PADS_LDS, s, "wide fwd last")
-                  : go(k_wide_fwd<NTW_, 1, K1, A, false, true, false, false>, P, Lp, dim3(grid), PADS_LDS, s, "wide fwd last");
+      if constexpr (BF)
+        return grad ? go(k_wide_fwd<NTW_, 1, K1, A, false, true, true, false, 1, FMT_IN16>, P, Lp, dim3(grid), PADS_LDS, s, "wide fwd last")
+                    : go(k_wide_fwd<NTW_, 1, K1, A, false, true, false, false, 1, FMT_IN16>, P, Lp, dim3(grid), PADS_LDS, s, "wide fwd last");
+      else
+        return grad ? go(k_wide_fwd<NTW_, 1, K1, A, false, true, true, false>, P, Lp, dim3(grid), PADS_LDS, s, "wide fwd last")
+                    : go(k_wide_fwd<NTW_, 1, K1, A, false, true, false, false>, P, Lp, dim3(grid), PADS_LDS, s, "wide fwd last");
   }
 }
 template <>
@@ -53,11 +59,15 @@ template <int K1, bool BF>
 static int bwd_k(int which, const FusedParams& P, const WideLayer& Lp, int grid, hipStream_t s) {
   constexpr int A = PINN_ACT_TANH;
   switch (which) {
-    case 0: return go(k_wide_bwd<NTW_, 1, K1, A, true, false, false>, P, Lp, dim3(grid), 0, s, "wide bwd first");
+    case 0:
+      if constexpr (BF) return go(k_wide_bwd<NTW_, 1, K1, A, true, false, false, 1, FMT_IN16 | FMT_GIN16 | FMT_OUT16>, P, Lp, dim3(grid), 0, s, "wide bwd first");
+      else return go(k_wide_bwd<NTW_, 1, K1, A, true, false, false>, P, Lp, dim3(grid), 0, s, "wide bwd first");
     case 1:
-      if constexpr (BF) return go2(k_wide_bwd<NTW_, NTW_, K1, A, true, true, true, 2>, P, Lp, dim3(grid), 0, s, "wide bwd hidden");
+      if constexpr (BF) return go2(k_wide_bwd<NTW_, NTW_, K1, A, true, true, true, 2, FMT_IN16 | FMT_GIN16 | FMT_OUT16>, P, Lp, dim3(grid), 0, s, "wide bwd hidden");
       else return go(k_wide_bwd<NTW_, NTW_, K1, A, true, true, false, 1>, P, Lp, dim3(grid), 0, s, "wide bwd hidden");
-    default: return go(k_wide_bwd<1, NTW_, K1, A, false, true, false>, P, Lp, dim3(grid), 0, s, "wide bwd last");
+    default:
+      if constexpr (BF) return go(k_wide_bwd<1, NTW_, K1, A, false, true, false, 1, FMT_OUT16>, P, Lp, dim3(grid), 0, s, "wide bwd last");
+      else return go(k_wide_bwd<1, NTW_, K1, A, false, true, false>, P, Lp, dim3(grid), 0, s, "wide bwd last");
   }
 }
 template <>
@@ -74,9 +84,9 @@ int launch_wide_bwd<NTW_>(int which, int K1, int prec, const FusedParams& P, con
 template <int K1, bool BF>
 static int wg_k(int which, const FusedParams& P, const WideLayer& Lp, int gx, hipStream_t s) {
   switch (which) {
-    case 0: return go(k_wide_wgrad<4, NTW_, 1, K1, true, false>, P, Lp, dim3(gx), PADS_LDS, s, "wide wgrad first");
-    case 1: return go(k_wide_wgrad<4, NTW_, NTW_, K1, false, BF>, P, Lp, dim3(gx), PADS_LDS, s, "wide wgrad hidden");
-    default: return go(k_wide_wgrad<1, 1, NTW_, K1, false, false>, P, Lp, dim3(gx), PADS_LDS, s, "wide wgrad last");
+    case 0: return go(k_wide_wgrad<4, NTW_, 1, K1, true, false, BF ? FMT_GIN16 : 0>, P, Lp, dim3(gx), PADS_LDS, s, "wide wgrad first");
+    case 1: return go(k_wide_wgrad<4, NTW_, NTW_, K1, false, BF, BF ? (FMT_IN16 | FMT_GIN16) : 0>, P, Lp, dim3(gx), PADS_LDS, s, "wide wgrad hidden");
+    default: return go(k_wide_wgrad<1, 1, NTW_, K1, false, false, BF ? FMT_IN16 : 0>, P, Lp, dim3(gx), PADS_LDS, s, "wide wgrad last");
   }
 }
 template <>

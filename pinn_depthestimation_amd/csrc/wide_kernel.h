@@ -60,6 +60,31 @@ __device__ __forceinline__ bf16x4 load_w16(const unsigned short* __restrict__ W1
   return *reinterpret_cast<const bf16x4*>(W16 + idx);
 }
 
+// ---- jet storage format.  In bf16 mode the per-layer kernels are bound by the HBM traffic of the jets
+// (512 KB per 16-point tile and layer in fp32), and every stored jet is only ever consumed as a bf16
+// MFMA operand or by the activation adjoint, so they are STORED as bf16 too (half the traffic).  The
+// output adjoint G of the (fp32) output layer stays fp32.  FMT bits per kernel:
+constexpr int FMT_IN16 = 1;    // Lp.in_act holds bf16
+constexpr int FMT_GIN16 = 2;   // Lp.g_in holds bf16
+constexpr int FMT_OUT16 = 4;   // what the kernel writes (out_act / g_out / z_out) is bf16
+__device__ __forceinline__ f4 from_bf16x4(bf16x4 v) {
+  f4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = __builtin_bit_cast(float, (unsigned)(unsigned short)v[i] << 16);
+  return o;
+}
+// block = one 16x16 tile of one quantity (256 elements), fragment-native: element lane*4 + r
+template <bool H>
+__device__ __forceinline__ f4 jet_ld(const float* base, int64_t blk, int lane) {
+  if constexpr (H) return from_bf16x4(*reinterpret_cast<const bf16x4*>(reinterpret_cast<const unsigned short*>(base) + blk * 256 + lane * 4));
+  else return *reinterpret_cast<const f4*>(base + blk * 256 + lane * 4);
+}
+template <bool H>
+__device__ __forceinline__ void jet_st(float* base, int64_t blk, int lane, f4 v) {
+  if constexpr (H) *reinterpret_cast<bf16x4*>(reinterpret_cast<unsigned short*>(base) + blk * 256 + lane * 4) = to_bf16x4(v);
+  else *reinterpret_cast<f4*>(base + blk * 256 + lane * 4) = v;
+}
+
 // acc[c][MT] += W[16MT + m][16(kc+j) ..] . B[c][j] for every output tile MT of one input chunk.
 // The weight fragments of tile MT+1 are requested before the MFMAs of tile MT issue (one wave per
 // SIMD: an L2 round trip per output tile would otherwise sit exposed 16 times per chunk).
@@ -120,7 +145,7 @@ __device__ __forceinline__ void wide_input_jet(const FusedParams& P, int64_t ptc
 // HV = 2: the output tiles of one 16-point tile are split between two waves (NTO/2 accumulator tiles
 // = 128 registers each), so two waves fit per SIMD and cover each other's load latencies; both read
 // the same input jet (second read served by L1/L2).
-template <int NTI, int NTO_ALL, int K1, int ACT, bool FIRST, bool LAST, bool GRAD, bool BF16, int HV = 1>
+template <int NTI, int NTO_ALL, int K1, int ACT, bool FIRST, bool LAST, bool GRAD, bool BF16, int HV = 1, int FMT = 0>
 __global__ __launch_bounds__(WIDE_THREADS * HV, HV) void k_wide_fwd(const FusedParams P, const WideLayer Lq) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) / HV, hf = (threadIdx.x >> 6) % HV;
@@ -151,7 +176,7 @@ __global__ __launch_bounds__(WIDE_THREADS * HV, HV) void k_wide_fwd(const FusedP
       for (int c = 0; c < K1; ++c)
 #pragma unroll
         for (int j = 0; j < CH; ++j)
-          Bc[c][j] = *reinterpret_cast<const f4*>(Lp.in_act + ((t * K1 + c) * NTI + kc + j) * 256 + lane * 4);
+          Bc[c][j] = jet_ld<(FMT & FMT_IN16) != 0>(Lp.in_act, (t * K1 + c) * NTI + kc + j, lane);
     };
     for (int kc = 0; kc < NTI; kc += CH) {
       f4 B[K1][CH];
@@ -171,7 +196,7 @@ __global__ __launch_bounds__(WIDE_THREADS * HV, HV) void k_wide_fwd(const FusedP
       for (int c = 0; c < K1; ++c)
 #pragma unroll
         for (int MT = 0; MT < NTO; ++MT)
-          *reinterpret_cast<f4*>(Lp.out_act + ((t * K1 + c) * NTO_ALL + hf * NTO + MT) * 256 + lane * 4) = acc[c][MT];
+          jet_st<(FMT & FMT_OUT16) != 0>(Lp.out_act, (t * K1 + c) * NTO_ALL + hf * NTO + MT, lane, acc[c][MT]);
     } else {
       static_assert(!LAST || NTO == 1, "the output layer has one (padded) tile");
       f4 (&out)[K1][1] = acc;
@@ -205,7 +230,7 @@ __global__ __launch_bounds__(WIDE_THREADS * HV, HV) void k_wide_fwd(const FusedP
 // NTK = tiles of the layer OUTPUT (the contraction axis here), NTO = tiles of the layer INPUT.
 // HV = 2 as in k_wide_fwd (input-feature tiles split between two waves).  zbar goes to z_out, never
 // back over g_in: with two waves per tile an in-place update would be read twice.
-template <int NTK, int NTO_ALL, int K1, int ACT, bool HIDDEN, bool NEED_GIN, bool BF16, int HV = 1>
+template <int NTK, int NTO_ALL, int K1, int ACT, bool HIDDEN, bool NEED_GIN, bool BF16, int HV = 1, int FMT = 0>
 __global__ __launch_bounds__(WIDE_THREADS * HV, HV) void k_wide_bwd(const FusedParams P, const WideLayer Lq) {
   const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) / HV, hf = (threadIdx.x >> 6) % HV;
   const int p = lane & 15, q = lane >> 4;
@@ -232,14 +257,14 @@ __global__ __launch_bounds__(WIDE_THREADS * HV, HV) void k_wide_bwd(const FusedP
       for (int c = 0; c < K1; ++c)
 #pragma unroll
         for (int j = 0; j < CH; ++j)
-          g[c][j] = *reinterpret_cast<const f4*>((HV == 1 ? Lp.g_in : gin_p) + ((t * K1 + c) * NTK + kc + j) * 256 + lane * 4);
+          g[c][j] = jet_ld<(FMT & FMT_GIN16) != 0>(HV == 1 ? Lp.g_in : gin_p, (t * K1 + c) * NTK + kc + j, lane);
       if constexpr (HIDDEN) {
         f4 ao[K1][CH];
 #pragma unroll
         for (int c = 0; c < K1; ++c)
 #pragma unroll
           for (int j = 0; j < CH; ++j)
-            ao[c][j] = *reinterpret_cast<const f4*>(act_p + ((t * K1 + c) * NTK + kc + j) * 256 + lane * 4);
+            ao[c][j] = jet_ld<(FMT & FMT_IN16) != 0>(act_p, (t * K1 + c) * NTK + kc + j, lane);
         activate_adjoint<ACT, CH, K1>(g, ao);
         // HV == 1: in place through the SAME pointer the loads use (the compiler then knows the store
         // cannot alias the next chunk's loads); HV == 2: separate buffer, written by one of the two waves
@@ -249,7 +274,7 @@ __global__ __launch_bounds__(WIDE_THREADS * HV, HV) void k_wide_bwd(const FusedP
           for (int c = 0; c < K1; ++c)
 #pragma unroll
             for (int j = 0; j < CH; ++j)
-              *reinterpret_cast<f4*>(zdst + ((t * K1 + c) * NTK + kc + j) * 256 + lane * 4) = g[c][j];
+              jet_st<(FMT & FMT_OUT16) != 0>(zdst, (t * K1 + c) * NTK + kc + j, lane, g[c][j]);
         }
       }
       if constexpr (NEED_GIN) wide_mac_chunk<CH, K1, NTO, BF16>(Lp, kc, LDW, p, q, g, acc);
@@ -259,7 +284,7 @@ __global__ __launch_bounds__(WIDE_THREADS * HV, HV) void k_wide_bwd(const FusedP
       for (int c = 0; c < K1; ++c)
 #pragma unroll
         for (int MT = 0; MT < NTO; ++MT)
-          *reinterpret_cast<f4*>(gout_p + ((t * K1 + c) * NTO_ALL + hf * NTO + MT) * 256 + lane * 4) = acc[c][MT];
+          jet_st<(FMT & FMT_OUT16) != 0>(gout_p, (t * K1 + c) * NTO_ALL + hf * NTO + MT, lane, acc[c][MT]);
     }
   }
 }
@@ -269,7 +294,7 @@ __global__ __launch_bounds__(WIDE_THREADS * HV, HV) void k_wide_bwd(const FusedP
 // and re-read from L1/L2 (as separate workgroups they landed on different XCDs and the kernel ran
 // at the HBM roof re-reading them).
 // NTM = output tiles of the layer, NTN = input tiles.  FIRST: the layer input is (x, tangents).
-template <int MTB, int NTM, int NTN, int K1, bool FIRST, bool BF16>
+template <int MTB, int NTM, int NTN, int K1, bool FIRST, bool BF16, int FMT = 0>
 __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_wgrad(const FusedParams P, const WideLayer Lp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -301,10 +326,10 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_wgrad(const FusedParam
     auto fetch = [&](int64_t t, int c) {
 #pragma unroll
       for (int MT = 0; MT < MTB; ++MT)
-        rz[MT] = *reinterpret_cast<const f4*>(Lp.g_in + ((t * K1 + c) * NTM + rb * MTB + MT) * 256 + lane * 4);
+        rz[MT] = jet_ld<(FMT & FMT_GIN16) != 0>(Lp.g_in, (t * K1 + c) * NTM + rb * MTB + MT, lane);
 #pragma unroll
       for (int i = 0; i < APW; ++i)
-        ra[i] = *reinterpret_cast<const f4*>(Lp.in_act + ((t * K1 + c) * NTN + wave * APW + i) * 256 + lane * 4);
+        ra[i] = jet_ld<(FMT & FMT_IN16) != 0>(Lp.in_act, (t * K1 + c) * NTN + wave * APW + i, lane);
     };
     if (gw < Lp.n_tiles) fetch(gw, 0);
     int buf = 0;
@@ -362,7 +387,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_wgrad(const FusedParam
   auto fetch = [&](int64_t t, int c) {
 #pragma unroll
     for (int MT = 0; MT < MTB; ++MT)
-      rz[MT] = *reinterpret_cast<const f4*>(Lp.g_in + ((t * K1 + c) * NTM + rb * MTB + MT) * 256 + lane * 4);
+      rz[MT] = jet_ld<(FMT & FMT_GIN16) != 0>(Lp.g_in, (t * K1 + c) * NTM + rb * MTB + MT, lane);
     if constexpr (FIRST) {
       const int64_t pt = (Lp.tile0 + t) * 16 + p;
       f4 b0[K1][1];
@@ -372,7 +397,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_wgrad(const FusedParam
     } else {
 #pragma unroll
       for (int NT = 0; NT < NTN; ++NT)
-        ra[NT] = *reinterpret_cast<const f4*>(Lp.in_act + ((t * K1 + c) * NTN + NT) * 256 + lane * 4);
+        ra[NT] = jet_ld<(FMT & FMT_IN16) != 0>(Lp.in_act, (t * K1 + c) * NTN + NT, lane);
     }
   };
   // (fp32 mode: the 256 MFMAs per quantity leave no registers for the look-ahead — measured 30 %
