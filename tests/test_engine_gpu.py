@@ -21,6 +21,10 @@ CASES = {
     "pe_8x64": (2, 6, 8, 64, (0, 1), "physics_equation", ("x", "y"), ("h", "U", "V", "eta_mean", "Hrms", "k")),
     "cf_4x20": (2, 3, 4, 20, (0, 1), "continuity_ftemp", ("x", "y"), ("U", "V", "h")),
     "co_4x20": (2, 3, 4, 20, (0, 1), "continuity_only", ("x", "y"), ("U", "V", "h")),
+    # padded width 64 (where the tile / cooperative / paired kernels differ): shallow nets, every residual family
+    "ns_1x64": (3, 4, 1, 64, (0, 1, 2), "Navier_Stokes", ("t", "x", "y"), ("h", "z", "u", "v")),
+    "ns_2x48": (3, 4, 2, 48, (0, 1, 2), "Navier_Stokes", ("t", "x", "y"), ("h", "z", "u", "v")),
+    "co_3x64": (2, 3, 3, 64, (0, 1), "continuity_only", ("x", "y"), ("U", "V", "h")),
 }
 
 
@@ -109,9 +113,10 @@ def test_residual_loss_grad(name, engine):
     assert rel_l2(grad.cpu(), g64) < max(2e-5, 4 * gnoise)
 
 
+@pytest.mark.parametrize("case", ["pe_10x10", "pe_8x64"])
 @pytest.mark.parametrize("engine", ENGINES)
-def test_mse_loss_grad(engine):
-    layers, params, X, desc, *_ = make_case("pe_10x10", 12)
+def test_mse_loss_grad(engine, case):
+    layers, params, X, desc, *_ = make_case(case, 12)
     g = torch.Generator().manual_seed(7)
     T = torch.rand(12, 6, generator=g)
     w = [1.0, 2.0, 0.5, 1.0, 3.0, 1.0]
@@ -187,11 +192,12 @@ def test_adam_step_matches_torch():
         assert torch.equal(pd.cpu(), ref.detach()), f"step {step}: max diff {(pd.cpu()-ref.detach()).abs().max()}"
 
 
+@pytest.mark.parametrize("case", ["co_4x20", "co_3x64"])
 @pytest.mark.parametrize("engine", ENGINES)
-def test_residual_and_mse_in_one_pass(engine):
+def test_residual_and_mse_in_one_pass(engine, case):
     """pinn_residual_mse_loss_grad (train_newmethod.py:122-159: one forward feeds both terms) equals the
     two separate calls on the same points."""
-    layers, params, X, desc, res, inn, outn = make_case("co_4x20", 555)
+    layers, params, X, desc, res, inn, outn = make_case(case, 555)
     X[:, 0] = X[:, 0] * 40
     g = torch.Generator().manual_seed(8)
     T = torch.rand(555, 2, generator=g).cuda()
