@@ -17,6 +17,7 @@
  *                           fused with loss.backward() (train.py:154,191)
  *   pinn_mse_loss_grad      train.py:131-141 (weighted fidelity MSE) + backward
  *   pinn_residual_mse_loss_grad  train_newmethod.py:122-159 (both on one forward) + backward
+ *   pinn_residual_mse_split_loss_grad  train.py:131-157 (fidelity set + collocation set, one launch)
  *   pinn_adam_step          torch.optim.Adam.step as called at train.py:192
  *
  * Conventions
@@ -156,6 +157,19 @@ int32_t pinn_residual_mse_loss_grad(const pinn_desc* desc, const pinn_residual_s
                                     const float* params, const float* X, int64_t N,
                                     float* term_sums, float* col_sums, float* grad_flat,
                                     void* ws, int64_t ws_bytes, void* stream);
+
+/* train.py:131-157 in ONE launch: the reference's loss_func runs the network twice per iteration, on
+ * the fidelity points (train.py:132-141) and on the collocation points (train.py:148-154).  Here X
+ * holds the n_res collocation points FIRST and the N - n_res fidelity points after them; T holds
+ * the fidelity targets only, (N - n_res, n_cols).  The residual terms are summed over the first
+ * n_res points, the squared errors over the rest (fidelity points ride through the jet kernels
+ * with unused tangents: meant for N_fid << N_res or small N, where launches dominate). */
+int32_t pinn_residual_mse_split_loss_grad(const pinn_desc* desc, const pinn_residual_spec* spec,
+                                          const float* term_scale, const float* T, int32_t n_cols,
+                                          const int32_t* out_col, const float* col_scale,
+                                          const float* params, const float* X, int64_t N, int64_t n_res,
+                                          float* term_sums, float* col_sums, float* grad_flat,
+                                          void* ws, int64_t ws_bytes, void* stream);
 
 /* torch.optim.Adam single-tensor update on flat buffers (amsgrad off, weight_decay 0,
  * maximize off): m,v are exp_avg / exp_avg_sq; step is the 1-based step count;

@@ -30,7 +30,8 @@ int make_net(const pinn_desc* d, Net* n);  // validates, returns PINN_OK or erro
 
 // what a loss call asks the engines for
 struct LossReq {
-  int kind;  // 0 = residual, 1 = mse, 2 = residual + mse on the same points (one pass)
+  int kind;  // 0 = residual, 1 = mse, 2 = residual + mse in one pass
+  int64_t n_split;  // kind 2: < 0 both terms on every point; >= 0 residual on points [0, n_split), mse on [n_split, N)
   pinn_residual_spec spec;
   const float* scale;   // residual: device term_scale (may be null when !want_grad)
   float* sums;          // residual: device term_sums

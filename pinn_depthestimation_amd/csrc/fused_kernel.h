@@ -67,7 +67,8 @@ struct FusedParams {
   const float* scale;        // residual: device term scales (null when no gradient wanted)
   int n_cols;                // mse: number of target columns
   int mse_col[PINN_MAX_ROLES];   // mse: output column of each target column
-  const float* T;            // mse: targets (N, n_cols)
+  const float* T;            // mse: targets (N, n_cols); split mode: (N - n_split, n_cols)
+  int64_t n_split;           // < 0: every loss term on every point; >= 0: residual on points < n_split, mse on the rest
   const float* mse_scale;    // mse: device column scales
   float* wg_sums;            // [grid][MAX_SUMS]
   float* wg_grads;           // acc_lds: [grid][PP]; else [nrep][PP] (atomics)
@@ -558,15 +559,18 @@ __device__ __forceinline__ void loss_epilogue(const FusedParams& P, const f4 (&o
   }
 #pragma unroll
   for (int c = 0; c < K1; ++c) G[c][0] = f4{0.f, 0.f, 0.f, 0.f};
+  // split mode (train.py:131-157 in one launch): collocation points first, fidelity points after them
+  const bool valid_r = valid && (P.n_split < 0 || pt < P.n_split);
+  const bool valid_m = valid && (P.n_split < 0 || pt >= P.n_split);
   if (P.loss_kind & 1) {
     if (P.residual_id == PINN_RES_NAVIER_STOKES) {
-      if constexpr (K1 >= 4) residual_tile<ResNavierStokes, K1, GRAD>(P, out, G, sums, sm, tb, valid, false, p, q, primary);
+      if constexpr (K1 >= 4) residual_tile<ResNavierStokes, K1, GRAD>(P, out, G, sums, sm, tb, valid_r, false, p, q, primary);
     } else if (P.residual_id == PINN_RES_PHYSICS_EQUATION) {
-      if constexpr (K1 >= 3) residual_tile<ResPhysicsEquation, K1, GRAD>(P, out, G, sums, sm, tb, valid, false, p, q, primary);
+      if constexpr (K1 >= 3) residual_tile<ResPhysicsEquation, K1, GRAD>(P, out, G, sums, sm, tb, valid_r, false, p, q, primary);
     } else {
       if constexpr (K1 >= 3) {
         const bool masked = P.residual_id == PINN_RES_CONTINUITY_ONLY && P.X[ptc * P.d_in + P.xcol] < P.thr;
-        residual_tile<ResContinuity, K1, GRAD>(P, out, G, sums, sm, tb, valid, masked, p, q, primary);
+        residual_tile<ResContinuity, K1, GRAD>(P, out, G, sums, sm, tb, valid_r, masked, p, q, primary);
       }
     }
   }
@@ -577,12 +581,13 @@ __device__ __forceinline__ void loss_epilogue(const FusedParams& P, const f4 (&o
       gm[0][j] = 0.f;
       if (j < P.n_cols) {
         const float y = gather_out(out[0][0], P.mse_col[j], p);
-        const float d = P.T[ptc * P.n_cols + j] - y;                  // train.py:141 (true - pred)
-        if (valid && q == 0 && primary) sums[MSE_SUM0 + j] += d * d;
+        const int64_t trow = (P.n_split > 0 && valid_m) ? ptc - P.n_split : (P.n_split > 0 ? 0 : ptc);
+        const float d = P.T[trow * P.n_cols + j] - y;                 // train.py:141 (true - pred)
+        if (valid_m && q == 0 && primary) sums[MSE_SUM0 + j] += d * d;
         if (GRAD) gm[0][j] = -2.f * P.mse_scale[j] * d;
       }
     }
-    if constexpr (GRAD) scatter_adjoint<K1, 1, PINN_MAX_ROLES, true>(tb, gm, sm_mse, G, valid, p, q);
+    if constexpr (GRAD) scatter_adjoint<K1, 1, PINN_MAX_ROLES, true>(tb, gm, sm_mse, G, valid_m, p, q);
   }
 }
 

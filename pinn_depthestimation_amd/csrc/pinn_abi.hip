@@ -190,7 +190,7 @@ static int32_t residual_impl(const pinn_desc* desc, const pinn_residual_spec* sp
     set_error("NULL pointer argument"); return PINN_ERR_INVALID;
   }
   LossReq rq; memset(&rq, 0, sizeof(rq));
-  rq.kind = 0; rq.spec = *spec; rq.scale = term_scale; rq.sums = term_sums;
+  rq.kind = 0; rq.n_split = -1; rq.spec = *spec; rq.scale = term_scale; rq.sums = term_sums;
   rq.grad = want_grad ? grad_flat : nullptr; rq.n_terms = residual_terms(spec->residual_id);
   if (N == 0) { (void)hipMemsetAsync(term_sums, 0, rq.n_terms * sizeof(float), (hipStream_t)stream); return PINN_OK; }
   const int e = pick_engine(desc, n, &rc); if (rc) return rc;
@@ -219,7 +219,7 @@ int32_t pinn_mse_loss_grad(const pinn_desc* desc, const float* params, const flo
   }
   if (n_cols < 1 || n_cols > PINN_MAX_ROLES) { set_error("n_cols=%d outside 1..%d", n_cols, PINN_MAX_ROLES); return PINN_ERR_INVALID; }
   LossReq rq; memset(&rq, 0, sizeof(rq));
-  rq.kind = 1; rq.T = T; rq.n_cols = n_cols; rq.mse_scale = col_scale; rq.mse_sums = col_sums; rq.grad = grad_flat;
+  rq.kind = 1; rq.n_split = -1; rq.T = T; rq.n_cols = n_cols; rq.mse_scale = col_scale; rq.mse_sums = col_sums; rq.grad = grad_flat;
   for (int j = 0; j < n_cols; ++j) {
     if (out_col[j] < 0 || out_col[j] >= n.d_out) { set_error("out_col[%d]=%d out of range", j, out_col[j]); return PINN_ERR_INVALID; }
     rq.out_col[j] = out_col[j];
@@ -232,19 +232,20 @@ int32_t pinn_mse_loss_grad(const pinn_desc* desc, const float* params, const flo
                                : generic_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream);
 }
 
-int32_t pinn_residual_mse_loss_grad(const pinn_desc* desc, const pinn_residual_spec* spec, const float* term_scale,
+static int32_t residual_mse_impl(int64_t n_split, const pinn_desc* desc, const pinn_residual_spec* spec, const float* term_scale,
                                     const float* T, int32_t n_cols, const int32_t* out_col, const float* col_scale,
                                     const float* params, const float* X, int64_t N, float* term_sums,
                                     float* col_sums, float* grad_flat, void* ws, int64_t ws_bytes, void* stream) {
   Net n; int rc = make_net(desc, &n); if (rc) return rc;
   rc = check_spec(n, spec); if (rc) return rc;
-  if (!params || ((!X || !T) && N > 0) || N < 0 || !term_sums || !col_sums || !out_col || !grad_flat || !term_scale ||
+  if (n_split > N) { set_error("n_res=%lld exceeds N=%lld", (long long)n_split, (long long)N); return PINN_ERR_INVALID; }
+  if (!params || ((!X || (!T && n_split != N)) && N > 0) || N < 0 || !term_sums || !col_sums || !out_col || !grad_flat || !term_scale ||
       !col_scale) {
     set_error("NULL pointer argument"); return PINN_ERR_INVALID;
   }
   if (n_cols < 1 || n_cols > PINN_MAX_ROLES) { set_error("n_cols=%d outside 1..%d", n_cols, PINN_MAX_ROLES); return PINN_ERR_INVALID; }
   LossReq rq; memset(&rq, 0, sizeof(rq));
-  rq.kind = 2; rq.spec = *spec; rq.scale = term_scale; rq.sums = term_sums; rq.n_terms = residual_terms(spec->residual_id);
+  rq.kind = 2; rq.n_split = n_split; rq.spec = *spec; rq.scale = term_scale; rq.sums = term_sums; rq.n_terms = residual_terms(spec->residual_id);
   rq.T = T; rq.n_cols = n_cols; rq.mse_scale = col_scale; rq.mse_sums = col_sums; rq.grad = grad_flat;
   for (int j = 0; j < n_cols; ++j) {
     if (out_col[j] < 0 || out_col[j] >= n.d_out) { set_error("out_col[%d]=%d out of range", j, out_col[j]); return PINN_ERR_INVALID; }
@@ -255,10 +256,32 @@ int32_t pinn_residual_mse_loss_grad(const pinn_desc* desc, const pinn_residual_s
     (void)hipMemsetAsync(col_sums, 0, n_cols * sizeof(float), (hipStream_t)stream);
     return PINN_OK;
   }
+  if (n_split == N) {   // no fidelity points: the residual-only pass (T may be NULL)
+    rq.kind = 0; rq.n_split = -1;
+    (void)hipMemsetAsync(col_sums, 0, n_cols * sizeof(float), (hipStream_t)stream);
+  }
   const int e = pick_engine(desc, n, &rc); if (rc) return rc;
   return e == PINN_ENGINE_FUSED ? fused_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream)
        : e == PINN_ENGINE_WIDE ? wide_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream)
                                : generic_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int32_t pinn_residual_mse_loss_grad(const pinn_desc* desc, const pinn_residual_spec* spec, const float* term_scale,
+                                    const float* T, int32_t n_cols, const int32_t* out_col, const float* col_scale,
+                                    const float* params, const float* X, int64_t N, float* term_sums,
+                                    float* col_sums, float* grad_flat, void* ws, int64_t ws_bytes, void* stream) {
+  return residual_mse_impl(-1, desc, spec, term_scale, T, n_cols, out_col, col_scale, params, X, N, term_sums, col_sums,
+                           grad_flat, ws, ws_bytes, stream);
+}
+
+int32_t pinn_residual_mse_split_loss_grad(const pinn_desc* desc, const pinn_residual_spec* spec, const float* term_scale,
+                                          const float* T, int32_t n_cols, const int32_t* out_col, const float* col_scale,
+                                          const float* params, const float* X, int64_t N, int64_t n_res,
+                                          float* term_sums, float* col_sums, float* grad_flat, void* ws,
+                                          int64_t ws_bytes, void* stream) {
+  if (n_res < 0) { set_error("n_res must be >= 0"); return PINN_ERR_INVALID; }
+  return residual_mse_impl(n_res, desc, spec, term_scale, T, n_cols, out_col, col_scale, params, X, N, term_sums,
+                           col_sums, grad_flat, ws, ws_bytes, stream);
 }
 
 int32_t pinn_adam_step(float* params, const float* grad, float* m, float* v, int64_t P, int64_t step, double lr,

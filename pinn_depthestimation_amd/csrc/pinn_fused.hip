@@ -54,7 +54,8 @@ bool pair_default() {   // read per call (the tests flip it)
   const char* e = getenv("PINN_FUSED_PAIR");
   return e ? (atoi(e) != 0) : (PINN_FUSED_PAIR_DEFAULT != 0);
 }
-bool use_pair(const Net& n, const Geo& g, bool grad) {
+bool use_pair(const Net& n, const Geo& g, bool grad, bool split = false) {
+  if (split) return false;   // the paired kernel's epilogue has no split mode
   if (g.WP != 64 || (n.K1 != 2 && n.K1 != 4)) return false;
   if (grad && (int64_t)g.PP * 4 + pair_lds_fixed_bytes() > LDS_LIMIT) return false;
   if (grad && n.K1 == 2) return true;   // k_fused has no K1 = 2 gradient kernel
@@ -206,6 +207,7 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
   P.d_in = n.d_in; P.d_out = n.d_out; P.L = n.L; P.act = n.act;
   for (int j = 0; j < PINN_MAX_DIRS; ++j) P.dir_col[j] = n.dir_col[j];
   P.N = N; P.n_tiles = (N + 15) / 16;
+  P.n_split = rq ? rq->n_split : -1;
   P.X = X;
   P.Wp = (const float*)(base + w.wp); P.WTp = (const float*)(base + w.wtp); P.Bp = (const float*)(base + w.bp);
   P.scratch = (float*)(base + w.scratch);
@@ -235,7 +237,7 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
     }
   }
   const bool coop = use_coop(n, g, grad, N);
-  const bool pair = !coop && use_pair(n, g, grad);
+  const bool pair = !coop && use_pair(n, g, grad, rq && rq->n_split >= 0);
   if (coop) {
     P.acc_lds = grad ? 1 : 0;
     P.lds_acc_floats = grad ? g.PP : 0;

@@ -200,13 +200,13 @@ template <class RES, bool GRAD>
 __global__ void k_residual(const float* __restrict__ yj, int d_out, int64_t N, RoleMap rm,
                            const float* __restrict__ scale, const float* __restrict__ X, int d_in, int xcol,
                            int anchor_on, float thr, float anchor, float* __restrict__ G,
-                           float* __restrict__ partial) {
+                           float* __restrict__ partial, int64_t n_res) {
   constexpr int NR = RES::NR, ND = RES::ND, NT = RES::NT;
   int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float sq[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) sq[t] = 0.f;
-  if (n < N) {
+  if (n < n_res) {   // (split mode: only the first n_res points are collocation points)
     float v[1 + ND][NR], g[1 + ND][NR];
 #pragma unroll
     for (int c = 0; c <= ND; ++c) {
@@ -239,17 +239,17 @@ __global__ void k_residual(const float* __restrict__ yj, int d_out, int64_t N, R
 struct MseMap { int n_cols; int out_col[PINN_MAX_ROLES]; };
 template <bool GRAD>
 __global__ void k_mse(const float* __restrict__ y, int d_out, int64_t N, MseMap mm, const float* __restrict__ T,
-                      const float* __restrict__ scale, float* __restrict__ G, float* __restrict__ partial) {
+                      const float* __restrict__ scale, float* __restrict__ G, float* __restrict__ partial, int64_t n0) {
   int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float sq[PINN_MAX_ROLES];
 #pragma unroll
   for (int j = 0; j < PINN_MAX_ROLES; ++j) sq[j] = 0.f;
-  if (n < N) {
+  if (n >= n0 && n < N) {   // (split mode: fidelity points start at n0; T holds their rows only)
 #pragma unroll
     for (int j = 0; j < PINN_MAX_ROLES; ++j) {
       if (j < mm.n_cols) {
         const int64_t idx = (int64_t)mm.out_col[j] * N + n;
-        const float d = T[n * mm.n_cols + j] - y[idx];
+        const float d = T[(n - n0) * mm.n_cols + j] - y[idx];
         sq[j] = d * d;
         if (GRAD) G[idx] += -2.f * scale[j] * d;  // G pre-zeroed; += lets two targets share a column
       }
@@ -380,6 +380,8 @@ int run_loss(const Net& n, const LossReq& rq, const float* params, const float* 
   float* partial = (float*)(ws + lo.partial);
   const bool want_grad = rq.grad != nullptr;
   if (want_grad) (void)hipMemsetAsync(G, 0, (size_t)K1 * n.d_out * N * 4, s);
+  const int64_t n_res = (rq.kind == 2 && rq.n_split >= 0) ? rq.n_split : N;
+  const int64_t n0 = (rq.kind == 2 && rq.n_split >= 0) ? rq.n_split : 0;
   if (rq.kind == 0 || rq.kind == 2) {
     int nt_stride = 0;
     RoleMap rm;
@@ -391,10 +393,10 @@ int run_loss(const Net& n, const LossReq& rq, const float* params, const float* 
     nt_stride = RES::NT;                                                                                       \
     if (want_grad)                                                                                             \
       hipLaunchKernelGGL((k_residual<RES, true>), dim3(grid), dim3(TPB), 0, s, out, n.d_out, N, rm, rq.scale, X, \
-                         n.d_in, XCOL, ANCH, rq.spec.param[0], rq.spec.param[1], G, partial);                  \
+                         n.d_in, XCOL, ANCH, rq.spec.param[0], rq.spec.param[1], G, partial, n_res);           \
     else                                                                                                       \
       hipLaunchKernelGGL((k_residual<RES, false>), dim3(grid), dim3(TPB), 0, s, out, n.d_out, N, rm, rq.scale, X, \
-                         n.d_in, XCOL, ANCH, rq.spec.param[0], rq.spec.param[1], G, partial);                  \
+                         n.d_in, XCOL, ANCH, rq.spec.param[0], rq.spec.param[1], G, partial, n_res);           \
   } while (0)
     if (id == PINN_RES_NAVIER_STOKES) LAUNCH_RES(ResNavierStokes, 0, 0);
     else if (id == PINN_RES_PHYSICS_EQUATION) LAUNCH_RES(ResPhysicsEquation, 0, 0);
@@ -408,8 +410,8 @@ int run_loss(const Net& n, const LossReq& rq, const float* params, const float* 
   if (rq.kind == 1 || rq.kind == 2) {   // fidelity columns; adds into G (pre-zeroed / after the residual's writes)
     MseMap mm; mm.n_cols = rq.n_cols;
     for (int j = 0; j < PINN_MAX_ROLES; ++j) mm.out_col[j] = j < rq.n_cols ? rq.out_col[j] : 0;
-    if (want_grad) hipLaunchKernelGGL(k_mse<true>, dim3(grid), dim3(TPB), 0, s, out, n.d_out, N, mm, rq.T, rq.mse_scale, G, partial);
-    else hipLaunchKernelGGL(k_mse<false>, dim3(grid), dim3(TPB), 0, s, out, n.d_out, N, mm, rq.T, rq.mse_scale, G, partial);
+    if (want_grad) hipLaunchKernelGGL(k_mse<true>, dim3(grid), dim3(TPB), 0, s, out, n.d_out, N, mm, rq.T, rq.mse_scale, G, partial, n0);
+    else hipLaunchKernelGGL(k_mse<false>, dim3(grid), dim3(TPB), 0, s, out, n.d_out, N, mm, rq.T, rq.mse_scale, G, partial, n0);
     hipLaunchKernelGGL(k_reduce_partials, dim3(rq.n_cols), dim3(256), 0, s, (const float*)partial, lo.nblocks,
                        PINN_MAX_ROLES, rq.n_cols, rq.mse_sums);
   }

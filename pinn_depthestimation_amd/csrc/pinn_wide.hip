@@ -114,6 +114,7 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
   P.d_in = n.d_in; P.d_out = n.d_out; P.L = n.L; P.act = n.act;
   for (int j = 0; j < PINN_MAX_DIRS; ++j) P.dir_col[j] = n.dir_col[j];
   P.N = N; P.X = X; P.Y = Y; P.dY = dY;
+  P.n_split = rq ? rq->n_split : -1;
   P.wg_sums = (float*)(base + w.sums);
   if (rq) {
     P.loss_kind = rq->kind == 0 ? 1 : (rq->kind == 1 ? 2 : 3);

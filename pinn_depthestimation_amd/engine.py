@@ -270,6 +270,27 @@ class Engine:
                                                    self._stream()), "pinn_residual_mse_loss_grad")
         return term_sums, col_sums
 
+    def residual_mse_split_loss_grad(self, spec: ResidualSpec, term_scale, T: torch.Tensor, out_col: Sequence[int],
+                                     col_scale, params, X, n_res: int, grad, engine=None, term_sums=None,
+                                     col_sums=None):
+        """train.py:131-157 in one launch: X = [n_res collocation points ; fidelity points], T = the
+        fidelity targets (N - n_res, n_cols)."""
+        N, nc = X.shape[0], len(out_col)
+        _chk(params, "params", (self.n_params,)); _chk(X, "X", (N, self.desc.d_in)); _chk(T, "T", (N - n_res, nc))
+        _chk(grad, "grad", (self.n_params,)); _chk(term_scale, "term_scale", (spec.n_terms,))
+        _chk(col_scale, "col_scale", (nc,))
+        if term_sums is None:
+            term_sums = torch.empty(spec.n_terms, dtype=torch.float32, device=X.device)
+        if col_sums is None:
+            col_sums = torch.empty(nc, dtype=torch.float32, device=X.device)
+        oc = (C.c_int32 * nc)(*out_col)
+        ws = self.workspace(N, engine)
+        check(self.lib.pinn_residual_mse_split_loss_grad(
+            C.byref(self._d(engine)), C.byref(spec.c_struct()), _ptr(term_scale), _ptr(T), nc, oc, _ptr(col_scale),
+            _ptr(params), _ptr(X), N, int(n_res), _ptr(term_sums), _ptr(col_sums), _ptr(grad), _ptr(ws), ws.numel(),
+            self._stream()), "pinn_residual_mse_split_loss_grad")
+        return term_sums, col_sums
+
     def adam_step(self, params, grad, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8):
         for t, nme in ((params, "params"), (grad, "grad"), (m, "exp_avg"), (v, "exp_avg_sq")):
             _chk(t, nme, (self.n_params,))

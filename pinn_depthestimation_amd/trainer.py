@@ -43,8 +43,21 @@ class HipEvaluator:
         act = ACTIVATION_OF_INIT[init_type]
         self.eng = Engine(NetDesc.from_layers(cfg_layers, grad_cols, act, engine), device)
         self.spec, self.fid_cols = spec, list(fid_cols)
+        self.merge_sets = True      # one launch for both loss terms when the fidelity set is small
+        self._cat, self._cat_key = None, None
+
+    MERGE_MAX_FID = 2048   # fidelity points ride through the jet kernel (4x their own work): only when few
 
     def __call__(self, theta, Xf, Tf, fid_scale, Xr, res_scale, grad, fid_sums, res_sums):
+        if (self.merge_sets and Xf is not None and Xr is not None and Xf is not Xr
+                and 0 < Xf.shape[0] <= self.MERGE_MAX_FID and Xr.shape[0] > 0):
+            # train.py:131-157 in ONE launch: collocation points first, fidelity points after them
+            key = (Xr.data_ptr(), Xf.data_ptr(), Xr.shape[0], Xf.shape[0])
+            if self._cat_key != key:
+                self._cat, self._cat_key = torch.cat((Xr, Xf), 0).contiguous(), key
+            self.eng.residual_mse_split_loss_grad(self.spec, res_scale, Tf, self.fid_cols, fid_scale, theta, self._cat,
+                                                  Xr.shape[0], grad, term_sums=res_sums, col_sums=fid_sums)
+            return
         if Xf is not None and Xf is Xr and Xr.shape[0] > 0:
             # one point set for both terms (train_newmethod.py:122-159): one pass, one forward
             self.eng.residual_mse_loss_grad(self.spec, res_scale, Tf, self.fid_cols, fid_scale, theta, Xr, grad,

@@ -250,3 +250,40 @@ def test_forward_and_jet_odd_shapes_all_engines(shape):
         grad = torch.zeros(desc.n_params, device="cuda")
         eng.jet_backward(flat, Xd, gY.cuda(), gdY.cuda(), grad)
         assert rel_l2(grad.cpu(), go) < 3e-5
+
+
+@pytest.mark.parametrize("case", ["ns_8x64", "pe_10x10", "co_3x64", "cf_4x20"])
+@pytest.mark.parametrize("engine", ENGINES)
+def test_split_pass_equals_residual_plus_fidelity_calls(engine, case):
+    """pinn_residual_mse_split_loss_grad (train.py:131-157 in one launch: collocation points first, fidelity
+    points after them) equals pinn_residual_loss_grad on the first set plus pinn_mse_loss_grad on the second."""
+    n_res, n_fid = 333, 45          # neither a multiple of a tile; the boundary falls inside a tile
+    layers, params, X, desc, res, inn, outn = make_case(case, n_res + n_fid)
+    if res == "continuity_only":
+        X[:, 0] = X[:, 0] * 40
+    nc = min(3, desc.d_out)
+    g = torch.Generator().manual_seed(11)
+    T = torch.rand(n_fid, nc, generator=g).cuda()
+    eng = Engine(desc.with_(engine=engine))
+    spec = ResidualSpec.from_names(res, inn, desc.grad_cols, outn)
+    flat, Xd = O.flatten(params).cuda(), X.cuda().contiguous()
+    ts = torch.full((spec.n_terms,), 1.0 / n_res).cuda()
+    if res == "continuity_only":
+        ts = torch.tensor([1.0 / n_res, 1.0 / max(float((X[:n_res, 0] < 25.5).sum()), 1.0), 0.0]).cuda()
+    cs = (torch.tensor([0.7, 1.3, 2.0][:nc]) / n_fid).cuda()
+    cols = list(range(nc))
+    g1 = torch.zeros(desc.n_params, device="cuda")
+    s_res = eng.residual_loss_grad(spec, ts, flat, Xd[:n_res].contiguous(), g1)
+    s_mse = eng.mse_loss_grad(flat, Xd[n_res:].contiguous(), T, cols, cs, g1)
+    g2 = torch.zeros(desc.n_params, device="cuda")
+    t_sums, c_sums = eng.residual_mse_split_loss_grad(spec, ts, T, cols, cs, flat, Xd, n_res, g2)
+    assert torch.allclose(t_sums, s_res, rtol=2e-6), (t_sums, s_res)
+    assert torch.allclose(c_sums, s_mse, rtol=2e-6), (c_sums, s_mse)
+    assert rel_l2(g2.cpu(), g1.cpu()) < 3e-6
+    # degenerate splits: no fidelity points / no collocation points
+    g3 = torch.zeros(desc.n_params, device="cuda")
+    t3, c3 = eng.residual_mse_split_loss_grad(spec, ts, T[:0], cols, cs, flat, Xd[:n_res].contiguous(), n_res, g3)
+    assert torch.allclose(t3, s_res, rtol=2e-6) and float(c3.abs().sum()) == 0.0
+    g4 = torch.zeros(desc.n_params, device="cuda")
+    t4, c4 = eng.residual_mse_split_loss_grad(spec, ts, T, cols, cs, flat, Xd[n_res:].contiguous(), 0, g4)
+    assert torch.allclose(c4, s_mse, rtol=2e-6) and float(t4[:2].abs().sum()) == 0.0
