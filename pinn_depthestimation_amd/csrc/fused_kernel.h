@@ -538,8 +538,8 @@ __device__ __forceinline__ void build_scatter_maps(const FusedParams& P, int q, 
 
 // Everything that happens on the output tile of one 16-point tile: optional Y/dY stores, PDE
 // residual and/or fidelity MSE (train.py:131-157), loss partial sums, output adjoint G.
-template <int K1, bool GRAD>
-__device__ __forceinline__ void loss_epilogue(const FusedParams& P, const f4 (&out)[K1][1], f4 (&G)[K1][1],
+template <int K1, bool GRAD, bool SPLIT>
+__device__ __forceinline__ void loss_epilogue_impl(const FusedParams& P, const f4 (&out)[K1][1], f4 (&G)[K1][1],
                                               float (&sums)[MAX_SUMS], const ScatterMap<K1>& sm,
                                               const ScatterMap<K1>& sm_mse, float* __restrict__ tb, int64_t pt,
                                               int64_t ptc, bool valid, int p, int q, bool primary = true) {
@@ -560,8 +560,10 @@ __device__ __forceinline__ void loss_epilogue(const FusedParams& P, const f4 (&o
 #pragma unroll
   for (int c = 0; c < K1; ++c) G[c][0] = f4{0.f, 0.f, 0.f, 0.f};
   // split mode (train.py:131-157 in one launch): collocation points first, fidelity points after them
-  const bool valid_r = valid && (P.n_split < 0 || pt < P.n_split);
-  const bool valid_m = valid && (P.n_split < 0 || pt >= P.n_split);
+  // SPLIT is a template parameter so that the common (unsplit) epilogue is untouched: even two extra
+  // compares in this register-starved region cost the 2^20-point step 0.5-2.5 % (measured)
+  const bool valid_r = SPLIT ? (valid && pt < P.n_split) : valid;
+  const bool valid_m = SPLIT ? (valid && pt >= P.n_split) : valid;
   if (P.loss_kind & 1) {
     if (P.residual_id == PINN_RES_NAVIER_STOKES) {
       if constexpr (K1 >= 4) residual_tile<ResNavierStokes, K1, GRAD>(P, out, G, sums, sm, tb, valid_r, false, p, q, primary);
@@ -581,7 +583,7 @@ __device__ __forceinline__ void loss_epilogue(const FusedParams& P, const f4 (&o
       gm[0][j] = 0.f;
       if (j < P.n_cols) {
         const float y = gather_out(out[0][0], P.mse_col[j], p);
-        const int64_t trow = (P.n_split > 0 && valid_m) ? ptc - P.n_split : (P.n_split > 0 ? 0 : ptc);
+        const int64_t trow = SPLIT ? (valid_m ? ptc - P.n_split : 0) : ptc;
         const float d = P.T[trow * P.n_cols + j] - y;                 // train.py:141 (true - pred)
         if (valid_m && q == 0 && primary) sums[MSE_SUM0 + j] += d * d;
         if (GRAD) gm[0][j] = -2.f * P.mse_scale[j] * d;
@@ -589,6 +591,24 @@ __device__ __forceinline__ void loss_epilogue(const FusedParams& P, const f4 (&o
     }
     if constexpr (GRAD) scatter_adjoint<K1, 1, PINN_MAX_ROLES, true>(tb, gm, sm_mse, G, valid_m, p, q);
   }
+}
+
+// SPLIT_OK = false leaves the split-mode code out of the kernel altogether: k_fused at width 64 is so
+// register-starved around the epilogue that even a never-taken second copy of it cost the 2^20-point
+// step 5 % (and two extra compares in the single copy 0.5-2.5 %); the host runs split requests that
+// would land on that kernel as two passes instead (pinn_fused.hip).
+template <int K1, bool GRAD, bool SPLIT_OK = true>
+__device__ __forceinline__ void loss_epilogue(const FusedParams& P, const f4 (&out)[K1][1], f4 (&G)[K1][1],
+                                              float (&sums)[MAX_SUMS], const ScatterMap<K1>& sm,
+                                              const ScatterMap<K1>& sm_mse, float* __restrict__ tb, int64_t pt,
+                                              int64_t ptc, bool valid, int p, int q, bool primary = true) {
+  if constexpr (SPLIT_OK) {
+    if (P.n_split >= 0) {
+      loss_epilogue_impl<K1, GRAD, true>(P, out, G, sums, sm, sm_mse, tb, pt, ptc, valid, p, q, primary);
+      return;
+    }
+  }
+  loss_epilogue_impl<K1, GRAD, false>(P, out, G, sums, sm, sm_mse, tb, pt, ptc, valid, p, q, primary);
 }
 
 // Diagnostic build only (-DPINN_DIAG): s_memtime stamps per phase, printed by wave 0 of block 0.
@@ -711,7 +731,7 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
 
     // ---- outputs / loss -----------------------------------------------------------------------
     f4 G[K1][1];
-    loss_epilogue<K1, GRAD>(P, out, G, sums, sm, sm_mse, tb, pt, ptc, valid, p, q);
+    loss_epilogue<K1, GRAD, (WP < 64)>(P, out, G, sums, sm, sm_mse, tb, pt, ptc, valid, p, q);
 
     PINN_STAMP(2);
     // ---- reverse sweep ------------------------------------------------------------------------
@@ -790,7 +810,7 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
 
     // ---- outputs / loss -----------------------------------------------------------------------
     f4 G[K1][1];
-    loss_epilogue<K1, GRAD>(P, out, G, sums, sm, sm_mse, tb, pt, ptc, valid, p, q);
+    loss_epilogue<K1, GRAD, (WP < 64)>(P, out, G, sums, sm, sm_mse, tb, pt, ptc, valid, p, q);
 
     PINN_STAMP(2);
     // ---- reverse sweep ------------------------------------------------------------------------

@@ -317,6 +317,23 @@ int fused_forward(const Net& n, const float* params, const float* X, int64_t N, 
 int fused_loss(const Net& n, const LossReq& rq, const float* params, const float* X, int64_t N, void* ws,
                int64_t ws_bytes, hipStream_t s) {
   const bool grad = rq.grad != nullptr;
+  if (rq.kind == 2 && rq.n_split >= 0) {
+    // Split mode lives in the cooperative kernel and the narrow (WP < 64) tile kernels only.  A
+    // request that would run on the width-64 tile kernel (large N, where a second launch is noise)
+    // is served as two passes on the same stream: residual on the collocation points, then the
+    // fidelity columns on the rest with the k = 0 network.
+    const Geo g = geo_of(n);
+    if (g.WP == 64 && !use_coop(n, g, grad, N)) {
+      LossReq r0 = rq; r0.kind = 0; r0.n_split = -1;
+      int rc = PINN_OK;
+      if (rq.n_split > 0) rc = fused_loss(n, r0, params, X, rq.n_split, ws, ws_bytes, s);
+      else (void)hipMemsetAsync(rq.sums, 0, rq.n_terms * sizeof(float), s);
+      if (rc) return rc;
+      LossReq r1 = rq; r1.kind = 1; r1.n_split = -1;
+      Net n1 = n; n1.k = 0; n1.K1 = 1;
+      return fused_loss(n1, r1, params, X + rq.n_split * n.d_in, N - rq.n_split, ws, ws_bytes, s);
+    }
+  }
   if (grad && n.K1 == 2 && !use_pair(n, geo_of(n), true)) {
     set_error("fused gradient kernels for K1 = 2 exist at hidden width 33..64 only"); return PINN_ERR_UNSUPPORTED;
   }
