@@ -538,11 +538,32 @@ __device__ __forceinline__ void build_scatter_maps(const FusedParams& P, int q, 
 
 // Everything that happens on the output tile of one 16-point tile: optional Y/dY stores, PDE
 // residual and/or fidelity MSE (train.py:131-157), loss partial sums, output adjoint G.
-template <int K1, bool GRAD, bool SPLIT>
+constexpr int EPI_GENERIC = 0, EPI_NS = 1, EPI_PE = 2, EPI_CONT = 3;
+
+template <int K1, bool GRAD, bool SPLIT, int EPI = EPI_GENERIC>
 __device__ __forceinline__ void loss_epilogue_impl(const FusedParams& P, const f4 (&out)[K1][1], f4 (&G)[K1][1],
                                               float (&sums)[MAX_SUMS], const ScatterMap<K1>& sm,
                                               const ScatterMap<K1>& sm_mse, float* __restrict__ tb, int64_t pt,
                                               int64_t ptc, bool valid, int p, int q, bool primary = true) {
+  // EPI != 0: an epilogue specialised to ONE residual family, residual loss only, no output stores.
+  // The generic epilogue keeps every family, the fidelity columns and the Y/dY stores behind runtime
+  // switches; at width 64 that costs 146 spilled SGPRs (372 v_readlane per tile) against 4 with the
+  // specialised form, and the 2^20-point Navier-Stokes step 1.1 % (6.89 -> 6.82 ms, same box).
+  if constexpr (EPI != EPI_GENERIC) {
+#pragma unroll
+    for (int c = 0; c < K1; ++c) G[c][0] = f4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == EPI_NS) {
+      if constexpr (K1 >= 4) residual_tile<ResNavierStokes, K1, GRAD>(P, out, G, sums, sm, tb, valid, false, p, q, primary);
+    } else if constexpr (EPI == EPI_PE) {
+      if constexpr (K1 >= 3) residual_tile<ResPhysicsEquation, K1, GRAD>(P, out, G, sums, sm, tb, valid, false, p, q, primary);
+    } else {
+      if constexpr (K1 >= 3) {
+        const bool masked = P.residual_id == PINN_RES_CONTINUITY_ONLY && P.X[ptc * P.d_in + P.xcol] < P.thr;
+        residual_tile<ResContinuity, K1, GRAD>(P, out, G, sums, sm, tb, valid, masked, p, q, primary);
+      }
+    }
+    return;
+  }
   // primary == false (cooperative kernel, waves 1..3): compute the output adjoint only — no stores, no sums
   if (P.Y != nullptr && valid && primary) {
 #pragma unroll
@@ -597,18 +618,18 @@ __device__ __forceinline__ void loss_epilogue_impl(const FusedParams& P, const f
 // register-starved around the epilogue that even a never-taken second copy of it cost the 2^20-point
 // step 5 % (and two extra compares in the single copy 0.5-2.5 %); the host runs split requests that
 // would land on that kernel as two passes instead (pinn_fused.hip).
-template <int K1, bool GRAD, bool SPLIT_OK = true>
+template <int K1, bool GRAD, bool SPLIT_OK = true, int EPI = EPI_GENERIC>
 __device__ __forceinline__ void loss_epilogue(const FusedParams& P, const f4 (&out)[K1][1], f4 (&G)[K1][1],
                                               float (&sums)[MAX_SUMS], const ScatterMap<K1>& sm,
                                               const ScatterMap<K1>& sm_mse, float* __restrict__ tb, int64_t pt,
                                               int64_t ptc, bool valid, int p, int q, bool primary = true) {
-  if constexpr (SPLIT_OK) {
+  if constexpr (SPLIT_OK && EPI == EPI_GENERIC) {
     if (P.n_split >= 0) {
       loss_epilogue_impl<K1, GRAD, true>(P, out, G, sums, sm, sm_mse, tb, pt, ptc, valid, p, q, primary);
       return;
     }
   }
-  loss_epilogue_impl<K1, GRAD, false>(P, out, G, sums, sm, sm_mse, tb, pt, ptc, valid, p, q, primary);
+  loss_epilogue_impl<K1, GRAD, false, EPI>(P, out, G, sums, sm, sm_mse, tb, pt, ptc, valid, p, q, primary);
 }
 
 // Diagnostic build only (-DPINN_DIAG): s_memtime stamps per phase, printed by wave 0 of block 0.
@@ -627,7 +648,7 @@ __device__ __forceinline__ void loss_epilogue(const FusedParams& P, const f4 (&o
 #define PINN_STAMP(i) do { } while (0)
 #endif
 
-template <int WP, int K1, bool GRAD, bool LDSACC, int ACT>
+template <int WP, int K1, bool GRAD, bool LDSACC, int ACT, int EPI = EPI_GENERIC>
 __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const FusedParams P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NTH = WP / 16;
@@ -731,7 +752,7 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
 
     // ---- outputs / loss -----------------------------------------------------------------------
     f4 G[K1][1];
-    loss_epilogue<K1, GRAD, (WP < 64)>(P, out, G, sums, sm, sm_mse, tb, pt, ptc, valid, p, q);
+    loss_epilogue<K1, GRAD, (WP < 64), EPI>(P, out, G, sums, sm, sm_mse, tb, pt, ptc, valid, p, q);
 
     PINN_STAMP(2);
     // ---- reverse sweep ------------------------------------------------------------------------
@@ -810,7 +831,7 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
 
     // ---- outputs / loss -----------------------------------------------------------------------
     f4 G[K1][1];
-    loss_epilogue<K1, GRAD, (WP < 64)>(P, out, G, sums, sm, sm_mse, tb, pt, ptc, valid, p, q);
+    loss_epilogue<K1, GRAD, (WP < 64), EPI>(P, out, G, sums, sm, sm_mse, tb, pt, ptc, valid, p, q);
 
     PINN_STAMP(2);
     // ---- reverse sweep ------------------------------------------------------------------------

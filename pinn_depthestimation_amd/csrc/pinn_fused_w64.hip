@@ -15,8 +15,32 @@ static int launch_one_act(const FusedParams& P, int grid, size_t lds, hipStream_
   return check_launch("fused kernel (WP=64)");
 }
 
+// residual-only gradient kernels with the epilogue specialised to one residual family (fused_kernel.h, EPI)
+template <int K1, int EPI>
+static int launch_special(const FusedParams& P, int grid, size_t lds, hipStream_t s) {
+  auto kern = k_fused<64, K1, true, true, PINN_ACT_TANH, EPI>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e)); return PINN_ERR_LAUNCH; }
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(FUSED_THREADS), lds, s, P);
+  return check_launch("fused kernel (WP=64, specialised epilogue)");
+}
+
 template <int K1, bool GRAD, bool LDSACC>
 static int launch_one(const FusedParams& P, int grid, size_t lds, hipStream_t s) {
+  if constexpr (GRAD && LDSACC && K1 >= 3) {
+    if (P.act == PINN_ACT_TANH && P.loss_kind == 1 && P.Y == nullptr && P.n_split < 0) {
+      if constexpr (K1 == 4) {
+        if (P.residual_id == PINN_RES_NAVIER_STOKES) return launch_special<4, EPI_NS>(P, grid, lds, s);
+      }
+      if constexpr (K1 == 3) {
+        if (P.residual_id == PINN_RES_PHYSICS_EQUATION) return launch_special<3, EPI_PE>(P, grid, lds, s);
+        if (P.residual_id == PINN_RES_CONTINUITY_ONLY || P.residual_id == PINN_RES_CONTINUITY_FTEMP)
+          return launch_special<3, EPI_CONT>(P, grid, lds, s);
+      }
+    }
+  }
   return P.act == PINN_ACT_TANH ? launch_one_act<K1, GRAD, LDSACC, PINN_ACT_TANH>(P, grid, lds, s)
                                 : launch_one_act<K1, GRAD, LDSACC, PINN_ACT_LEAKY_RELU>(P, grid, lds, s);
 }
