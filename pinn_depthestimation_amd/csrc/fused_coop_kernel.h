@@ -75,7 +75,7 @@ __device__ __forceinline__ void coop_adjoint(const f4 (&G)[K1], const f4 (&A)[K1
 }
 
 // One workgroup (4 waves) per 16-point tile; hidden width padded to 64.
-template <int K1, bool GRAD, int ACT>
+template <int K1, bool GRAD, int ACT, int EPI = EPI_GENERIC>
 __global__ __launch_bounds__(COOP_THREADS, 1) void k_fused_coop(const FusedParams P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int WP = 64, NTH = 4;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(COOP_THREADS, 1) void k_fused_coop(const FusedParam
 
     // ---- outputs / loss: every wave evaluates it (each needs the output adjoint); wave 0 stores and sums ----
     f4 G[K1][1];
-    loss_epilogue<K1, GRAD>(P, out, G, sums, sm, sm_mse, priv, pt, ptc, valid, p, q, primary);
+    loss_epilogue<K1, GRAD, true, EPI>(P, out, G, sums, sm, sm_mse, priv, pt, ptc, valid, p, q, primary);
 
     if constexpr (GRAD) {
       // ---- output layer L: dW_L columns 16w.., abar_L block w, zbar_{L-1} block w ------------------------

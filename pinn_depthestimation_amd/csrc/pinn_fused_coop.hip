@@ -16,8 +16,32 @@ static int launch_coop_act(const FusedParams& P, int grid, size_t lds, hipStream
   return check_launch("fused cooperative kernel");
 }
 
+// residual-only gradient kernels with the epilogue specialised to one residual family (fused_kernel.h, EPI)
+template <int K1, int EPI>
+static int launch_coop_special(const FusedParams& P, int grid, size_t lds, hipStream_t s) {
+  auto kern = k_fused_coop<K1, true, PINN_ACT_TANH, EPI>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e)); return PINN_ERR_LAUNCH; }
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(COOP_THREADS), lds, s, P);
+  return check_launch("fused cooperative kernel (specialised epilogue)");
+}
+
 template <int K1, bool GRAD>
 static int launch_coop(const FusedParams& P, int grid, size_t lds, hipStream_t s) {
+  if constexpr (GRAD && K1 >= 3) {
+    if (P.act == PINN_ACT_TANH && P.loss_kind == 1 && P.Y == nullptr && P.n_split < 0) {
+      if constexpr (K1 == 4) {
+        if (P.residual_id == PINN_RES_NAVIER_STOKES) return launch_coop_special<4, EPI_NS>(P, grid, lds, s);
+      }
+      if constexpr (K1 == 3) {
+        if (P.residual_id == PINN_RES_PHYSICS_EQUATION) return launch_coop_special<3, EPI_PE>(P, grid, lds, s);
+        if (P.residual_id == PINN_RES_CONTINUITY_ONLY || P.residual_id == PINN_RES_CONTINUITY_FTEMP)
+          return launch_coop_special<3, EPI_CONT>(P, grid, lds, s);
+      }
+    }
+  }
   return P.act == PINN_ACT_TANH ? launch_coop_act<K1, GRAD, PINN_ACT_TANH>(P, grid, lds, s)
                                 : launch_coop_act<K1, GRAD, PINN_ACT_LEAKY_RELU>(P, grid, lds, s);
 }
