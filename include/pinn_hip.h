@@ -18,6 +18,7 @@
  *   pinn_mse_loss_grad      train.py:131-141 (weighted fidelity MSE) + backward
  *   pinn_residual_mse_loss_grad  train_newmethod.py:122-159 (both on one forward) + backward
  *   pinn_residual_mse_split_loss_grad  train.py:131-157 (fidelity set + collocation set, one launch)
+ *   pinn_lbfgs_push / pinn_lbfgs_direction  torch.optim.LBFGS's two-loop recursion (train.py:116-125,200)
  *   pinn_adam_step          torch.optim.Adam.step as called at train.py:192
  *
  * Conventions
@@ -178,6 +179,18 @@ int32_t pinn_residual_mse_split_loss_grad(const pinn_desc* desc, const pinn_resi
 int32_t pinn_adam_step(float* params, const float* grad, float* m, float* v, int64_t P,
                        int64_t step, double lr, double beta1, double beta2, double eps,
                        void* stream);
+
+/* L-BFGS two-loop recursion of torch.optim.LBFGS (train.py:116-125, one .step(closure), train.py:200)
+ * on device.  S, Y: (m x P) row-major rings of steps and gradient differences, M = S Y^T (m x m, fp64,
+ * physical row indices); logical pair i (0 = oldest) is physical row (head + i) % m; k pairs in use.
+ * pinn_lbfgs_push stores (s, y) in row `slot` and refreshes row and column `slot` of M.
+ * pinn_lbfgs_direction writes d = -H_k g (H the initial scaling ys/yy); tmp: 4m doubles, coef: 2m
+ * floats, q: P floats of scratch.  Unused rows of S, Y must be zero.  m <= 256. */
+int32_t pinn_lbfgs_push(float* S, float* Y, double* M, int32_t m, int64_t P, int32_t slot,
+                        const float* s, const float* y, void* stream);
+int32_t pinn_lbfgs_direction(const float* S, const float* Y, const double* M, int32_t m, int64_t P,
+                             int32_t head, int32_t k, const float* g, double H, float* d,
+                             double* tmp, float* coef, float* q, void* stream);
 
 #ifdef __cplusplus
 }

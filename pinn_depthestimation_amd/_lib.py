@@ -61,6 +61,9 @@ _SIGNATURES = {
     "pinn_residual_mse_split_loss_grad": (C.c_int32, [C.POINTER(PinnDesc), C.POINTER(PinnResidualSpec), _P, _P, C.c_int32,
                                                       C.POINTER(C.c_int32), _P, _P, _P, C.c_int64, C.c_int64, _P, _P, _P,
                                                       _P, C.c_int64, _P]),
+    "pinn_lbfgs_push": (C.c_int32, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P]),
+    "pinn_lbfgs_direction": (C.c_int32, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, C.c_double, _P,
+                                         _P, _P, _P, _P]),
     "pinn_adam_step": (C.c_int32, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double,
                                    C.c_double, _P]),
 }

@@ -15,7 +15,8 @@ differences (oldest first), M = S Y^T and q0 = -g:
     d  = r0 + S^T w
 
 i.e. four (k x P) matrix-vector products, two k x k triangular solves (fp64), and two more
-products to extend M when a pair is stored.  Same arithmetic up to summation order; everything else
+products to extend M when a pair is stored.  On the GPU that is six launches of csrc/pinn_lbfgs.hip
+(`_HipHistory`); `_History` is the same formulation in torch operators (CPU, or no library).  Same arithmetic up to summation order; everything else
 (memory update rule, step-size initialisation, strong-Wolfe line search, stopping tests, state
 counters) is torch.optim.LBFGS's own: this class subclasses it, re-uses its helpers and its
 `_strong_wolfe`, and falls back to its `step` when it cannot apply.
@@ -71,6 +72,64 @@ class _History:
         return torch.addmv(q * H, self.S.t(), w.to(g.dtype))
 
 
+class _HipHistory:
+    """The same history on the device through libpinn_hip.so (csrc/pinn_lbfgs.hip): S, Y are rings
+    (no roll), the recursion is six launches (two row-dot passes, two one-wave triangular solves in
+    fp64, two combines) instead of ~25 torch operators."""
+
+    def __init__(self, m: int, like: torch.Tensor):
+        from . import _lib
+        import ctypes
+        self._C, self.lib = ctypes, _lib.load()
+        self.m, self.k, self.head, self.P = m, 0, 0, like.numel()
+        dev = like.device
+        self.S = torch.zeros(m, self.P, dtype=torch.float32, device=dev)
+        self.Y = torch.zeros_like(self.S)
+        self.M = torch.zeros(m, m, dtype=torch.float64, device=dev)
+        self.tmp = torch.zeros(4 * m, dtype=torch.float64, device=dev)
+        self.coef = torch.zeros(2 * m, dtype=torch.float32, device=dev)
+        self.q = torch.empty(self.P, dtype=torch.float32, device=dev)
+
+    def _p(self, t):
+        return self._C.c_void_p(t.data_ptr())
+
+    def _check(self, rc, what):
+        if rc != 0:
+            from ._lib import PinnError
+            raise PinnError(f"{what}: {self.lib.pinn_last_error().decode()}")
+
+    def push(self, s: torch.Tensor, y: torch.Tensor):
+        if self.k == self.m:
+            slot, self.head = self.head, (self.head + 1) % self.m      # overwrite the oldest pair
+        else:
+            slot = (self.head + self.k) % self.m
+            self.k += 1
+        s, y = s.contiguous(), y.contiguous()
+        st = self._C.c_void_p(torch.cuda.current_stream(s.device).cuda_stream)
+        self._check(self.lib.pinn_lbfgs_push(self._p(self.S), self._p(self.Y), self._p(self.M), self.m, self.P, slot,
+                                             self._p(s), self._p(y), st), "pinn_lbfgs_push")
+
+    def direction(self, g: torch.Tensor, H) -> torch.Tensor:
+        if self.k == 0:
+            return g.neg() * H
+        g = g.contiguous()
+        d = torch.empty_like(g)
+        st = self._C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream)
+        self._check(self.lib.pinn_lbfgs_direction(self._p(self.S), self._p(self.Y), self._p(self.M), self.m, self.P,
+                                                  self.head, self.k, self._p(g), float(H), self._p(d), self._p(self.tmp),
+                                                  self._p(self.coef), self._p(self.q), st), "pinn_lbfgs_direction")
+        return d
+
+
+def _make_history(m: int, like: torch.Tensor):
+    if like.is_cuda and like.dtype == torch.float32 and m <= 256:
+        try:
+            return _HipHistory(m, like)
+        except Exception:                 # library not built: the torch formulation below is the same arithmetic
+            pass
+    return _History(m, like)
+
+
 class FlatLBFGS(_TorchLBFGS):
     """torch.optim.LBFGS over ONE flat parameter tensor with the batched recursion above."""
 
@@ -107,7 +166,7 @@ class FlatLBFGS(_TorchLBFGS):
             state["n_iter"] += 1
             if state["n_iter"] == 1:
                 d = g.neg()
-                hist = _History(m, g)
+                hist = _make_history(m, g)
                 H = 1.0
             else:
                 if pending is None:                                       # (first iteration of a later .step call)

@@ -197,3 +197,20 @@ def test_every_reference_config_shape_trains(name, cfg):
     losses = np.array([h[3] for h in tr.history])
     assert len(losses) >= 4 and np.all(np.isfinite(losses)), (name, losses)
     assert losses[-1] < losses[0], (name, losses)
+
+
+def test_lbfgs_device_recursion_matches_torch_formulation():
+    """csrc/pinn_lbfgs.hip (ring history, six launches) against lbfgs._History (torch operators): same
+    direction, including after the ring has wrapped."""
+    from pinn_depthestimation_amd.lbfgs import _History, _HipHistory
+    P, m = 29636, 7
+    g = torch.Generator().manual_seed(3)
+    a, b = _History(m, torch.zeros(P, device="cuda")), _HipHistory(m, torch.zeros(P, device="cuda"))
+    for it in range(2 * m + 3):
+        s = (torch.randn(P, generator=g) * 1e-2).cuda()
+        y = s * (0.5 + torch.rand(P, generator=g).cuda()) + 1e-3 * torch.randn(P, generator=g).cuda()
+        a.push(s, y); b.push(s, y)
+        grad = torch.randn(P, generator=g).cuda()
+        H = float(y.dot(s) / y.dot(y))
+        da, db = a.direction(grad, H), b.direction(grad, H)
+        assert float((da - db).norm() / da.norm()) < 2e-5, it
