@@ -38,6 +38,12 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #ifndef PINN_FUSED_BATCH_FLUSH
 #define PINN_FUSED_BATCH_FLUSH 4   // row blocks of the LDS gradient flush read per round trip (0 = one block at a time)
 #endif
+#ifndef PINN_FUSED_ADJ_IN_FLUSH
+#define PINN_FUSED_ADJ_IN_FLUSH 0   // 1: run the activation adjoint between the LDS flush's reads and its adds
+#endif
+#ifndef PINN_FUSED_XPREF
+#define PINN_FUSED_XPREF 1   // 1: request the next tile's input coordinates one tile ahead
+#endif
 #ifndef PINN_FUSED_STREAM
 #define PINN_FUSED_STREAM 1   // streamed weights + copy-free layer loops (v6); 0 = the v5 prefetch structure
 #endif
@@ -359,9 +365,14 @@ struct GradSink {
 // dW[16MT + 4q + r][16NT + n] += sum_c sum_points Z[c][MT](feature, point) * A[c][NT](feature, point)
 // db[16MT + m]                += sum_points Z[0][MT](feature m, point)
 // A: the layer-input jet in acc layout (registers).
-template <int MT_N, int NT_N, int K1, class Sink>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// `between` (optional) runs after the flush's LDS reads have been issued and before their adds: vector
+// work that does not depend on the flush (the activation adjoint) then covers the LDS round trip.
+template <int MT_N, int NT_N, int K1, class Sink, class Hook = NoHook>
 __device__ __forceinline__ void weight_grad(const Sink& sink, int layer, int woff, int boff, const f4 (&Z)[K1][MT_N],
-                                            const f4 (&A)[K1][NT_N], float* __restrict__ tb, int lane) {
+                                            const f4 (&A)[K1][NT_N], float* __restrict__ tb, int lane,
+                                            const Hook& between = Hook()) {
   const int p = lane & 15, q = lane >> 4;
   f4 dw[MT_N][NT_N];
   float bs[MT_N];
@@ -419,6 +430,8 @@ __device__ __forceinline__ void weight_grad(const Sink& sink, int layer, int wof
         for (int NT = 0; NT < NT_N; ++NT)
           cur[MT - M0][NT] = *reinterpret_cast<const f4*>(sink.acc + woff + ((MT * NT_N + NT) * 64 + lane) * 4);
       __builtin_amdgcn_sched_barrier(0);
+      if (M0 == 0) between();
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int MT = M0; MT < M0 + FR && MT < MT_N; ++MT)
 #pragma unroll
@@ -426,6 +439,7 @@ __device__ __forceinline__ void weight_grad(const Sink& sink, int layer, int wof
           *reinterpret_cast<f4*>(sink.acc + woff + ((MT * NT_N + NT) * 64 + lane) * 4) = cur[MT - M0][NT] + dw[MT][NT];
     }
   } else {
+    between();
 #pragma unroll
     for (int MT = 0; MT < MT_N; ++MT)
 #pragma unroll
@@ -686,17 +700,38 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
 #ifdef PINN_DIAG
   unsigned long long diag[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #endif
+#if PINN_FUSED_XPREF
+  auto load_x = [&](int64_t t, f4& x) {
+    int64_t pc = t * 16 + p;
+    pc = pc < P.N ? pc : P.N - 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = 4 * q + r;
+      x[r] = (f < P.d_in) ? P.X[pc * P.d_in + f] : 0.f;
+    }
+  };
+  f4 xnext;
+  load_x(gw < P.n_tiles ? gw : 0, xnext);
+#endif
   for (int64_t tile = gw; tile < P.n_tiles; tile += nw) {
     PINN_STAMP(11);
     const int64_t pt = tile * 16 + p;
     const bool valid = pt < P.N;
     const int64_t ptc = valid ? pt : P.N - 1;
+#if PINN_FUSED_XPREF
+    const f4 xcur = xnext;
+    load_x(tile + nw < P.n_tiles ? tile + nw : tile, xnext);
+#endif
     // ---- layer-0 input jet: features 4q + r of (x, unit tangents) --------------------------
     auto input_jet = [&](f4 (&b)[K1][1]) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int f = 4 * q + r;
+#if PINN_FUSED_XPREF
+        b[0][0][r] = xcur[r];
+#else
         b[0][0][r] = (f < P.d_in) ? P.X[ptc * P.d_in + f] : 0.f;
+#endif
 #pragma unroll
         for (int c = 1; c < K1; ++c) b[c][0][r] = (f == P.dir_col[c - 1]) ? 1.f : 0.f;
       }
@@ -776,10 +811,18 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
         zero_tiles<NTH, K1>(g2);
         gemm_stream<NTH, NTH, K1>(WTp_ + w_off_p<WP>(l), WTp_ + w_off_p<WP>(l >= 2 ? l - 1 : 1), ws, z, g2, p, q);
         PINN_STAMP(6);
+#if PINN_FUSED_ADJ_IN_FLUSH
+        f4 zn[K1][NTH];
+        auto adj = [&]() { activate_adjoint_to<ACT, NTH, K1>(g2, ai, zn); };
+        weight_grad<NTH, NTH, K1>(sink, l, w_off_p<WP>(l), P.PW + b_off_p<WP>(l), z, ai, tb, lane, adj);
+        copy_tiles<NTH, K1>(z, zn);
+        if (l >= 2) unspill<NTH, K1>(scr + (l - 2) * SLOT, ai, lane);            // a_{l-1}
+#else
         weight_grad<NTH, NTH, K1>(sink, l, w_off_p<WP>(l), P.PW + b_off_p<WP>(l), z, ai, tb, lane);
         PINN_STAMP(5);
         activate_adjoint_to<ACT, NTH, K1>(g2, ai, z);
         if (l >= 2) unspill<NTH, K1>(scr + (l - 2) * SLOT, ai, lane);            // a_{l-1}
+#endif
         PINN_STAMP(4);
       }
       {  // layer 0: z = zbar_0, input = (x, unit tangents)
