@@ -41,6 +41,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #ifndef PINN_FUSED_ADJ_IN_FLUSH
 #define PINN_FUSED_ADJ_IN_FLUSH 0   // 1: run the activation adjoint between the LDS flush's reads and its adds
 #endif
+#ifndef PINN_FUSED_MID_IO
+#define PINN_FUSED_MID_IO 1   // spill stores / activation reloads issued from inside the GEMMs (see gemm_stream)
+#endif
 #ifndef PINN_FUSED_XPREF
 #define PINN_FUSED_XPREF 1   // 1: request the next tile's input coordinates one tile ahead
 #endif
@@ -132,15 +135,23 @@ __device__ __forceinline__ void load_wblk(const float* __restrict__ Wl, int MT, 
 // holds block 0 on entry; while the last block computes, block 0 of the NEXT phase's matrix
 // (`Wnext`, same row stride) is fetched into `wa`: its latency hides behind this GEMM's tail and
 // the vector work between the two GEMMs.
-template <int NT_IN, int NT_OUT, int K1>
+// `mid` (optional) is called once, right after block 1's prefetch has been issued (block 0 for short
+// GEMMs): the place for HBM traffic that must not sit in FRONT of a weight load in the in-order vmcnt
+// queue.  A spill store / activation reload issued before the GEMM has to complete before the first
+// streamed block (requested after it, consumed 2048 cycles later) can be used; issued here, the next
+// load behind it is consumed two blocks (4096 cycles) later and its own consumer a GEMM later.
+struct NoMid { __device__ __forceinline__ void operator()() const {} };
+template <int NT_IN, int NT_OUT, int K1, class Mid = NoMid>
 __device__ __forceinline__ void gemm_stream(const float* __restrict__ Wl, const float* __restrict__ Wnext,
                                             f4 (&wa)[NT_IN], const f4 (&bin)[K1][NT_IN], f4 (&acc)[K1][NT_OUT],
-                                            int m, int kq) {
+                                            int m, int kq, const Mid& mid = Mid()) {
+  constexpr int MID_BLOCK = NT_OUT >= 3 ? 1 : 0;
 #pragma unroll
   for (int MT = 0; MT < NT_OUT; ++MT) {
     f4 wb[NT_IN];
     if (MT + 1 < NT_OUT) load_wblk<NT_IN>(Wl, MT + 1, wb, m, kq);
     else load_wblk<NT_IN>(Wnext, 0, wb, m, kq);
+    if (MT == MID_BLOCK) mid();
 #pragma unroll
     for (int kt = 0; kt < NT_IN; ++kt)
 #pragma unroll
@@ -755,17 +766,27 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
       PINN_STAMP(0);
       activate_to<ACT, NTH, K1>(acc0, bias, a);
     }
+#if !PINN_FUSED_MID_IO
     if (GRAD && L > 1) spill<NTH, K1>(scr, a, lane);      // a_L itself stays in registers for the reverse sweep
+#endif
     PINN_STAMP(1);
     for (int l = 1; l < L; ++l) {
       f4 bias[NTH];
       load_bias<NTH>(Bp_ + b_off_p<WP>(l), bias, q);
       f4 nx[K1][NTH];
       zero_tiles<NTH, K1>(nx);
+#if PINN_FUSED_MID_IO
+      // a_l (this GEMM's B operand) is spilled from INSIDE the GEMM (see gemm_stream); a_L is never spilled
+      auto sp = [&]() { if (GRAD) spill<NTH, K1>(scr + (l - 1) * SLOT, a, lane); };
+      gemm_stream<NTH, NTH, K1>(Wp_ + w_off_p<WP>(l), Wp_ + w_off_p<WP>(l + 1), ws, a, nx, p, q, sp);
+      PINN_STAMP(0);
+      activate_to<ACT, NTH, K1>(nx, bias, a);
+#else
       gemm_stream<NTH, NTH, K1>(Wp_ + w_off_p<WP>(l), Wp_ + w_off_p<WP>(l + 1), ws, a, nx, p, q);
       PINN_STAMP(0);
       activate_to<ACT, NTH, K1>(nx, bias, a);
       if (GRAD && l < L - 1) spill<NTH, K1>(scr + l * SLOT, a, lane);   // (the last hidden jet is never re-read)
+#endif
       PINN_STAMP(1);
     }
     f4 out[K1][1];
@@ -782,7 +803,9 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
     f4 ai[K1][NTH];
     if constexpr (GRAD) {
       load_w<1, NTH>(WTp_ + w_off_p<WP>(L), wtl, p, q);
+#if !PINN_FUSED_MID_IO
       unspill<NTH, K1>(scr + (L > 1 ? L - 2 : 0) * SLOT, ai, lane);            // a_{L-1}
+#endif
     }
 
     // ---- outputs / loss -----------------------------------------------------------------------
@@ -809,19 +832,29 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const 
         PINN_STAMP(3);
         f4 g2[K1][NTH];
         zero_tiles<NTH, K1>(g2);
+#if PINN_FUSED_MID_IO
+        // a_l is requested from inside the GEMM (see gemm_stream) and used by the weight gradient after it
+        auto ld = [&]() { unspill<NTH, K1>(scr + (l - 1) * SLOT, ai, lane); };
+        gemm_stream<NTH, NTH, K1>(WTp_ + w_off_p<WP>(l), WTp_ + w_off_p<WP>(l >= 2 ? l - 1 : 1), ws, z, g2, p, q, ld);
+#else
         gemm_stream<NTH, NTH, K1>(WTp_ + w_off_p<WP>(l), WTp_ + w_off_p<WP>(l >= 2 ? l - 1 : 1), ws, z, g2, p, q);
+#endif
         PINN_STAMP(6);
 #if PINN_FUSED_ADJ_IN_FLUSH
         f4 zn[K1][NTH];
         auto adj = [&]() { activate_adjoint_to<ACT, NTH, K1>(g2, ai, zn); };
         weight_grad<NTH, NTH, K1>(sink, l, w_off_p<WP>(l), P.PW + b_off_p<WP>(l), z, ai, tb, lane, adj);
         copy_tiles<NTH, K1>(z, zn);
+#if !PINN_FUSED_MID_IO
         if (l >= 2) unspill<NTH, K1>(scr + (l - 2) * SLOT, ai, lane);            // a_{l-1}
+#endif
 #else
         weight_grad<NTH, NTH, K1>(sink, l, w_off_p<WP>(l), P.PW + b_off_p<WP>(l), z, ai, tb, lane);
         PINN_STAMP(5);
         activate_adjoint_to<ACT, NTH, K1>(g2, ai, z);
+#if !PINN_FUSED_MID_IO
         if (l >= 2) unspill<NTH, K1>(scr + (l - 2) * SLOT, ai, lane);            // a_{l-1}
+#endif
 #endif
         PINN_STAMP(4);
       }
