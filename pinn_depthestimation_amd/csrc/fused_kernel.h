@@ -411,14 +411,9 @@ __device__ __forceinline__ void weight_grad(const Sink& sink, int layer, int wof
     __builtin_amdgcn_sched_barrier(0);
     if (c + 1 < K1) stage(c + 1, zt[(c + 1) & 1], at[(c + 1) & 1]);
     __builtin_amdgcn_sched_barrier(0);
-    if (c == 0) {   // bias: zt[MT][s] = zbar(feature p, point 4s + q): sum the 4 regs, then the 4 lane groups
+    if (c == 0) {   // bias: zt[MT][s] = zbar(feature p, point 4s + q): sum the 4 regs here ...
 #pragma unroll
-      for (int MT = 0; MT < MT_N; ++MT) {
-        float t = (zt[0][MT][0] + zt[0][MT][1]) + (zt[0][MT][2] + zt[0][MT][3]);
-        t += __shfl_xor(t, 16, 64);
-        t += __shfl_xor(t, 32, 64);
-        bs[MT] = t;
-      }
+      for (int MT = 0; MT < MT_N; ++MT) bs[MT] = (zt[0][MT][0] + zt[0][MT][1]) + (zt[0][MT][2] + zt[0][MT][3]);
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -426,6 +421,15 @@ __device__ __forceinline__ void weight_grad(const Sink& sink, int layer, int wof
       for (int MT = 0; MT < MT_N; ++MT)
 #pragma unroll
         for (int NT = 0; NT < NT_N; ++NT) dw[MT][NT] = mfma4(zt[c & 1][MT][s], at[c & 1][NT][s], dw[MT][NT]);
+  }
+  // ... and the 4 lane groups here, after the last MFMA block: lgkmcnt retires in order, so a ds_bpermute
+  // issued right behind the next quantity's transposes would have made quantity 0's MFMAs wait for them
+#pragma unroll
+  for (int MT = 0; MT < MT_N; ++MT) {
+    float t = bs[MT];
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    bs[MT] = t;
   }
   sink.lock(layer, lane);
   if constexpr (Sink::LDS && PINN_FUSED_BATCH_FLUSH) {
