@@ -179,7 +179,7 @@ def main():
         kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
         traffic = None   # HBM bytes per launch from the committed PMC passes of this same command
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "fused_v9_pmc_summary.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "fused_v10_pmc_summary.json")))
             if args.engine in (0, 2) and args.workload == "ns8x64":
                 traffic = pm["hbm_bytes_per_point"] * N
         except Exception:
@@ -200,7 +200,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "traffic_source": ("rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, "
-                                            "profiles/r01/fused_v9_pmc_summary.json") if traffic is not None else None,
+                                            "profiles/r01/fused_v10_pmc_summary.json") if traffic is not None else None,
                          "kernel": "pinn_residual_loss_grad (fwd jet + residual + reverse sweep)",
                          "kernel_ms": kern_ms, "flop_per_point": flop_pt},
         }
