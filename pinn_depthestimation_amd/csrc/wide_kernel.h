@@ -88,15 +88,18 @@ __device__ __forceinline__ void jet_st(float* base, int64_t blk, int lane, f4 v)
 // acc[c][MT] += W[16MT + m][16(kc+j) ..] . B[c][j] for every output tile MT of one input chunk.
 // The weight fragments of tile MT+1 are requested before the MFMAs of tile MT issue (one wave per
 // SIMD: an L2 round trip per output tile would otherwise sit exposed 16 times per chunk).
-template <int CH, int K1, int NTO, bool BF16>
+// `mid`: the caller's zbar stores (k_wide_bwd), issued here rather than by the caller so that in bf16 mode
+// they go out after the operand conversions (4 % faster; fp32 keeps them in front of the chunk).
+template <int CH, int K1, int NTO, bool BF16, class Mid = NoMid>
 __device__ __forceinline__ void wide_mac_chunk(const WideLayer& Lp, int kc, int ldw, int p, int q, const f4 (&B)[K1][CH],
-                                               f4 (&acc)[K1][NTO]) {
+                                               f4 (&acc)[K1][NTO], const Mid& mid = Mid()) {
   if constexpr (BF16) {
     bf16x4 B16[K1][CH];
 #pragma unroll
     for (int c = 0; c < K1; ++c)
 #pragma unroll
       for (int j = 0; j < CH; ++j) B16[c][j] = to_bf16x4(B[c][j]);
+    mid();
     // (no look-ahead here: measured 12 % slower in bf16 mode, where the MFMA block per tile is short)
 #pragma unroll
     for (int MT = 0; MT < NTO; ++MT) {
@@ -109,6 +112,7 @@ __device__ __forceinline__ void wide_mac_chunk(const WideLayer& Lp, int kc, int 
         for (int c = 0; c < K1; ++c) acc[c][MT] = mfma_bf16(a[j], B16[c][j], acc[c][MT]);
     }
   } else {
+    mid();   // (fp32: in front of the chunk — from inside it, behind output tile 1's weights, measured 2 % slower)
     f4 a[2][CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) a[0][j] = *reinterpret_cast<const f4*>(Lp.W + p * ldw + 16 * (kc + j) + 4 * q);
@@ -268,16 +272,22 @@ __global__ __launch_bounds__(WIDE_THREADS * HV, HV) void k_wide_bwd(const FusedP
         activate_adjoint<ACT, CH, K1>(g, ao);
         // HV == 1: in place through the SAME pointer the loads use (the compiler then knows the store
         // cannot alias the next chunk's loads); HV == 2: separate buffer, written by one of the two waves
-        float* zdst = (HV == 1) ? Lp.g_in : zout_p;
-        if (hf == 0) {
-#pragma unroll
-          for (int c = 0; c < K1; ++c)
-#pragma unroll
-            for (int j = 0; j < CH; ++j)
-              jet_st<(FMT & FMT_OUT16) != 0>(zdst, (t * K1 + c) * NTK + kc + j, lane, g[c][j]);
-        }
       }
-      if constexpr (NEED_GIN) wide_mac_chunk<CH, K1, NTO, BF16>(Lp, kc, LDW, p, q, g, acc);
+      // zbar store: handed to the GEMM chunk, which decides where it goes (wide_mac_chunk)
+      auto zstore = [&]() {
+        if constexpr (HIDDEN) {
+          float* zdst = (HV == 1) ? Lp.g_in : zout_p;
+          if (hf == 0) {
+#pragma unroll
+            for (int c = 0; c < K1; ++c)
+#pragma unroll
+              for (int j = 0; j < CH; ++j)
+                jet_st<(FMT & FMT_OUT16) != 0>(zdst, (t * K1 + c) * NTK + kc + j, lane, g[c][j]);
+          }
+        }
+      };
+      if constexpr (NEED_GIN) wide_mac_chunk<CH, K1, NTO, BF16>(Lp, kc, LDW, p, q, g, acc, zstore);
+      else zstore();
     }
     if constexpr (NEED_GIN) {
 #pragma unroll
