@@ -44,6 +44,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #ifndef PINN_FUSED_MID_IO
 #define PINN_FUSED_MID_IO 1   // spill stores / activation reloads issued from inside the GEMMs (see gemm_stream)
 #endif
+#ifndef PINN_FUSED_W16_WAVES
+#define PINN_FUSED_W16_WAVES 3   // waves per SIMD the width-16 kernels are compiled for (workgroups per CU follow in pinn_fused.hip)
+#endif
 #ifndef PINN_FUSED_XPREF
 #define PINN_FUSED_XPREF 1   // 1: request the next tile's input coordinates one tile ahead
 #endif
@@ -678,7 +681,7 @@ __device__ __forceinline__ void loss_epilogue(const FusedParams& P, const f4 (&o
 #endif
 
 template <int WP, int K1, bool GRAD, bool LDSACC, int ACT, int EPI = EPI_GENERIC>
-__global__ __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4) void k_fused(const FusedParams P) {
+__global__ __launch_bounds__(FUSED_THREADS, WP == 16 ? PINN_FUSED_W16_WAVES : FUSED_WAVES / 4) void k_fused(const FusedParams P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NTH = WP / 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

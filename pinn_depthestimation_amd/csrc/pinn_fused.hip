@@ -79,9 +79,9 @@ bool use_coop(const Net& n, const Geo& g, bool grad, int64_t N) {
   return (N + 15) / 16 <= (int64_t)cu_count();
 }
 
-int grid_for(int64_t n_tiles, bool one_per_cu) {
+int grid_for(int64_t n_tiles, bool one_per_cu, int per_cu = 2) {
   int64_t want = (n_tiles + FUSED_WAVES - 1) / FUSED_WAVES;
-  int64_t cap = (int64_t)cu_count() * (one_per_cu ? 1 : 2);
+  int64_t cap = (int64_t)cu_count() * (one_per_cu ? 1 : per_cu);
   if (want < 1) want = 1;
   return (int)(want < cap ? want : cap);
 }
@@ -95,7 +95,7 @@ int64_t al(int64_t v) { return (v + 255) & ~(int64_t)255; }
 WsLayout ws_layout(const Net& n, const Geo& g, int64_t N) {
   WsLayout w;
   const int64_t n_tiles = (N + 15) / 16;
-  w.max_grid = grid_for(n_tiles, false);
+  w.max_grid = grid_for(n_tiles, false, g.WP == 16 && PINN_FUSED_W16_WAVES > 2 ? PINN_FUSED_W16_WAVES : 2);
   {   // the cooperative kernel launches one workgroup per tile (up to 2 per CU)
     const int64_t cap = 2 * (int64_t)cu_count();
     const int64_t coop_grid = n_tiles < cap ? n_tiles : cap;
@@ -253,7 +253,7 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
   // 8x64 gradient kernels fill the register file and most of LDS (1 workgroup per CU); the narrow
   // networks' kernels fit 2 waves per SIMD, which hides their per-layer latencies
   const bool one_per_cu = grad && P.acc_lds && !(g.WP <= 32 && 2 * (int64_t)lds <= LDS_LIMIT);
-  int grid = grid_for(P.n_tiles, one_per_cu);
+  int grid = grid_for(P.n_tiles, one_per_cu, g.WP == 16 && PINN_FUSED_W16_WAVES > 2 && (int64_t)PINN_FUSED_W16_WAVES * (int64_t)lds <= LDS_LIMIT ? PINN_FUSED_W16_WAVES : 2);
   if (coop) {   // one workgroup per tile, at most one per CU (gradient kernels fill the LDS)
     const int64_t cap = (int64_t)cu_count() * (grad ? 1 : 2);
     grid = (int)(P.n_tiles < cap ? (P.n_tiles < 1 ? 1 : P.n_tiles) : cap);
