@@ -332,7 +332,11 @@ constexpr int MAX_LOCKS = 128;
 //    measured ~150 cycles per wave-instruction on gfx950 and dominated the kernel; a plain
 //    ds_read_b128 / v_add / ds_write_b128 is ~free.  So each layer's block is guarded by a
 //    wave-level spin lock (one ds_cmpst by lane 0) and updated with plain vector RMW.
-//  !LDSACC (gradient too large for LDS): one of NREP global copies, global_atomic_add_f32.
+//  !LDSACC (gradient too large for LDS, e.g. the reference's 100x20 net): the workgroup's copy lives
+//    in global memory instead and is updated the same way, under the same LDS locks — plain vector
+//    read-modify-write; the waves of a workgroup share one CU's L1, so workgroup-scope fences are all
+//    the coherence it takes.  (global_atomic_add_f32 into 16 shared copies was 78 % of the 100x20 step:
+//    89.7 ms with, 20.0 ms without the atomics.)
 // Weight blocks are stored fragment-native: tile (MT, NT), lane, reg r holds
 // dW[16MT + 4(lane>>4) + r][16NT + (lane&15)]  at  woff + ((MT*NT_N + NT)*64 + lane)*4 + r.
 template <bool LDSACC>
@@ -341,38 +345,26 @@ struct GradSink {
   float* acc;
   int* locks;
   __device__ __forceinline__ void lock(int l, int lane) const {
-    if constexpr (LDSACC) {
-      if (lane == 0) {
-        int expected = 0;
-        while (!__hip_atomic_compare_exchange_strong(locks + l, &expected, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_WORKGROUP)) {
-          expected = 0;
-          __builtin_amdgcn_s_sleep(1);
-        }
+    if (lane == 0) {
+      int expected = 0;
+      while (!__hip_atomic_compare_exchange_strong(locks + l, &expected, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP)) {
+        expected = 0;
+        __builtin_amdgcn_s_sleep(1);
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
   }
   __device__ __forceinline__ void unlock(int l, int lane) const {
-    if constexpr (LDSACC) {
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) __hip_atomic_store(locks + l, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(locks + l, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
-  __device__ __forceinline__ void add1(int idx, float v) const {
-    if constexpr (LDSACC) acc[idx] += v;
-    else __hip_atomic_fetch_add(acc + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  __device__ __forceinline__ void add1(int idx, float v) const { acc[idx] += v; }
   __device__ __forceinline__ void add4(int idx, f4 v) const {   // idx: float index, multiple of 4
-    if constexpr (LDSACC) {
-      f4* ptr = reinterpret_cast<f4*>(acc + idx);
-      *ptr = *ptr + v;
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) __hip_atomic_fetch_add(acc + idx + r, v[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    f4* ptr = reinterpret_cast<f4*>(acc + idx);
+    *ptr = *ptr + v;
   }
 };
 
@@ -435,7 +427,7 @@ __device__ __forceinline__ void weight_grad(const Sink& sink, int layer, int wof
     bs[MT] = t;
   }
   sink.lock(layer, lane);
-  if constexpr (Sink::LDS && PINN_FUSED_BATCH_FLUSH) {
+  if constexpr (PINN_FUSED_BATCH_FLUSH != 0) {   // (LDS copy or global copy alike)
     // one LDS round trip per FLUSH_ROWS row blocks (all reads issued, then adds + writes) instead of
     // one per 16x16 block: with a single wave per SIMD the serialized read-add-write chain is exposed
     constexpr int FR = PINN_FUSED_BATCH_FLUSH < MT_N ? PINN_FUSED_BATCH_FLUSH : MT_N;
@@ -692,10 +684,12 @@ __global__ __launch_bounds__(FUSED_THREADS, WP == 16 ? PINN_FUSED_W16_WAVES : FU
   float* lsum = smem + P.lds_acc_floats + MAX_LOCKS + FUSED_WAVES * TB_PER_WAVE * TB_FLOATS;
   const int PP = P.PW + P.PB;
   GradSink<LDSACC> sink;
-  sink.acc = LDSACC ? lacc : P.wg_grads + (int64_t)(blockIdx.x % P.nrep) * PP;
+  sink.acc = LDSACC ? lacc : P.wg_grads + (int64_t)blockIdx.x * PP;
   sink.locks = locks;
-  if (GRAD && LDSACC) {
-    for (int i = threadIdx.x; i < PP; i += FUSED_THREADS) lacc[i] = 0.f;
+  if (GRAD) {
+    if (LDSACC) {
+      for (int i = threadIdx.x; i < PP; i += FUSED_THREADS) lacc[i] = 0.f;
+    }
     if (threadIdx.x < MAX_LOCKS) locks[threadIdx.x] = 0;
     __syncthreads();
   }

@@ -107,7 +107,7 @@ WsLayout ws_layout(const Net& n, const Geo& g, int64_t N) {
   w.bp = off; off += al((int64_t)g.PB * 4);
   w.scratch = off; off += al((int64_t)w.max_grid * FUSED_WAVES * n.L * g.slot_floats_k4 * 4);
   w.wg_sums = off; off += al((int64_t)w.max_grid * MAX_SUMS * 4);
-  const int64_t copies = fits_lds(g) ? w.max_grid : NREP;
+  const int64_t copies = w.max_grid;   // one (padded) gradient copy per workgroup, in LDS or — too large for it — here
   w.wg_grads = off; off += al(copies * g.PP * 4);
   w.total = off;
   return w;
@@ -266,8 +266,8 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
   const int packN = g.PW > g.PB ? g.PW : g.PB;
   hipLaunchKernelGGL(k_pack, dim3((packN + 255) / 256), dim3(256), 0, s, n, g.WP, params, (float*)(base + w.wp),
                      (float*)(base + w.wtp), (float*)(base + w.bp), g.PW, g.PB);
-  if (grad && !P.acc_lds) {
-    if (hipMemsetAsync(P.wg_grads, 0, (size_t)NREP * g.PP * 4, s) != hipSuccess) {
+  if (grad && !P.acc_lds) {   // the workgroups' global gradient copies start from zero
+    if (hipMemsetAsync(P.wg_grads, 0, (size_t)grid * g.PP * 4, s) != hipSuccess) {
       set_error("hipMemsetAsync failed"); return PINN_ERR_LAUNCH;
     }
   }
@@ -288,7 +288,7 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
       hipLaunchKernelGGL(k_reduce_sums, dim3(rq->n_cols), dim3(256), 0, s, (const float*)P.wg_sums, grid, MSE_SUM0,
                          rq->n_cols, rq->mse_sums);
     if (grad) {
-      const int copies = P.acc_lds ? grid : NREP;
+      const int copies = grid;
       const int64_t np = n.n_params();
       hipLaunchKernelGGL(k_reduce_grads, dim3((unsigned)((np + 63) / 64)), dim3(256), 0, s, n, g.WP,
                          (const float*)P.wg_grads, copies, g.PP, g.PW, rq->grad);
