@@ -47,6 +47,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #ifndef PINN_FUSED_W16_WAVES
 #define PINN_FUSED_W16_WAVES 3   // waves per SIMD the width-16 kernels are compiled for (workgroups per CU follow in pinn_fused.hip)
 #endif
+#ifndef PINN_FUSED_EARLY_LOCK
+#define PINN_FUSED_EARLY_LOCK 1   // global gradient copy: lock + request the current values before the dW MFMAs
+#endif
 #ifndef PINN_FUSED_XPREF
 #define PINN_FUSED_XPREF 1   // 1: request the next tile's input coordinates one tile ahead
 #endif
@@ -386,6 +389,18 @@ __device__ __forceinline__ void weight_grad(const Sink& sink, int layer, int wof
   for (int MT = 0; MT < MT_N; ++MT)
 #pragma unroll
     for (int NT = 0; NT < NT_N; ++NT) dw[MT][NT] = f4{0.f, 0.f, 0.f, 0.f};
+  // Global gradient copy (!Sink::LDS): take the layer's lock and request the current values NOW, so
+  // that the global round trip hides behind the transposes and MFMAs below instead of sitting in the
+  // flush (waves of a workgroup are on different layers almost always: holding the lock longer is free).
+  f4 early[Sink::LDS ? 1 : MT_N][Sink::LDS ? 1 : NT_N];
+  if constexpr (!Sink::LDS && PINN_FUSED_EARLY_LOCK) {
+    sink.lock(layer, lane);
+#pragma unroll
+    for (int MT = 0; MT < MT_N; ++MT)
+#pragma unroll
+      for (int NT = 0; NT < NT_N; ++NT)
+        early[MT][NT] = *reinterpret_cast<const f4*>(sink.acc + woff + ((MT * NT_N + NT) * 64 + lane) * 4);
+  }
   // Transposes run one quantity AHEAD of the MFMAs that consume them: the LDS round trip of
   // quantity c+1 (same pads: quantity c's reads have already landed in registers) overlaps the
   // MT_N*NT_N*4 MFMAs of quantity c.
@@ -426,6 +441,13 @@ __device__ __forceinline__ void weight_grad(const Sink& sink, int layer, int wof
     t += __shfl_xor(t, 32, 64);
     bs[MT] = t;
   }
+  if constexpr (!Sink::LDS && PINN_FUSED_EARLY_LOCK) {
+#pragma unroll
+    for (int MT = 0; MT < MT_N; ++MT)
+#pragma unroll
+      for (int NT = 0; NT < NT_N; ++NT)
+        *reinterpret_cast<f4*>(sink.acc + woff + ((MT * NT_N + NT) * 64 + lane) * 4) = early[MT][NT] + dw[MT][NT];
+  } else {
   sink.lock(layer, lane);
   if constexpr (PINN_FUSED_BATCH_FLUSH != 0) {   // (LDS copy or global copy alike)
     // one LDS round trip per FLUSH_ROWS row blocks (all reads issued, then adds + writes) instead of
@@ -454,6 +476,7 @@ __device__ __forceinline__ void weight_grad(const Sink& sink, int layer, int wof
     for (int MT = 0; MT < MT_N; ++MT)
 #pragma unroll
       for (int NT = 0; NT < NT_N; ++NT) sink.add4(woff + ((MT * NT_N + NT) * 64 + lane) * 4, dw[MT][NT]);
+  }
   }
   if (q == 0) {
 #pragma unroll
