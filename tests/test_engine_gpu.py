@@ -25,6 +25,9 @@ CASES = {
     "ns_1x64": (3, 4, 1, 64, (0, 1, 2), "Navier_Stokes", ("t", "x", "y"), ("h", "z", "u", "v")),
     "ns_2x48": (3, 4, 2, 48, (0, 1, 2), "Navier_Stokes", ("t", "x", "y"), ("h", "z", "u", "v")),
     "co_3x64": (2, 3, 3, 64, (0, 1), "continuity_only", ("x", "y"), ("U", "V", "h")),
+    # deep and narrow (three of the reference's four configs are 20-100 layers of width 20): the padded
+    # gradient no longer fits LDS and is accumulated in per-workgroup global copies
+    "cf_40x20": (2, 3, 40, 20, (0, 1), "continuity_ftemp", ("x", "y"), ("U", "V", "h")),
 }
 
 
