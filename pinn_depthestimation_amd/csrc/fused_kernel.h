@@ -86,8 +86,8 @@ struct FusedParams {
   int64_t n_split;           // < 0: every loss term on every point; >= 0: residual on points < n_split, mse on the rest
   const float* mse_scale;    // mse: device column scales
   float* wg_sums;            // [grid][MAX_SUMS]
-  float* wg_grads;           // acc_lds: [grid][PP]; else [nrep][PP] (atomics)
-  int acc_lds, nrep;
+  float* wg_grads;           // [grid][PP]: acc_lds: written once at kernel end; else the workgroups' live global copies
+  int acc_lds, nrep;         // (nrep: unused since the global-atomic path went; kept so the struct layout is unchanged)
   int PW, PB;                // padded weight / bias float counts
   int lds_acc_floats;        // floats reserved for the LDS gradient copy (0 if unused)
 };
