@@ -17,10 +17,16 @@ struct Net {
   int n_lin;  // L + 1 linear layers
   __host__ __device__ int in_dim(int l) const { return l == 0 ? d_in : W; }
   __host__ __device__ int out_dim(int l) const { return l == L ? d_out : W; }
-  __host__ __device__ int64_t w_off(int l) const {  // offset of W_l in the flat parameter vector
-    int64_t off = 0;
-    for (int i = 0; i < l; ++i) off += (int64_t)in_dim(i) * out_dim(i) + out_dim(i);
-    return off;
+  __host__ __device__ int64_t w_off(int l) const {  // offset of W_l in the flat parameter vector (O(1): 100-layer nets)
+    if (l == 0) return 0;
+    const int64_t hid = (int64_t)d_in * W + W + (int64_t)((l <= L ? l : L) - 1) * ((int64_t)W * W + W);   // layer 0 + hidden blocks
+    return l <= L ? hid : hid + (int64_t)W * d_out + d_out;                                        // l == L + 1: the total
+  }
+  __host__ __device__ int layer_of(int64_t i) const {   // which layer's block holds flat parameter index i
+    const int64_t s0 = (int64_t)d_in * W + W, per = (int64_t)W * W + W;
+    if (i < s0) return 0;
+    const int64_t l = 1 + (i - s0) / per;
+    return l < L ? (int)l : L;
   }
   __host__ __device__ int64_t b_off(int l) const { return w_off(l) + (int64_t)in_dim(l) * out_dim(l); }
   __host__ __device__ int64_t n_params() const { return w_off(L + 1); }

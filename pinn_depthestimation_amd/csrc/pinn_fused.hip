@@ -169,12 +169,8 @@ __global__ void k_reduce_grads(Net n, int WP, const float* __restrict__ wg, int 
   const int64_t i = (int64_t)blockIdx.x * 64 + lane_p;
   float s = 0.f;
   if (i < n.n_params()) {
-    int l = 0; int64_t off = 0;
-    for (;; ++l) {
-      const int64_t sz = (int64_t)n.in_dim(l) * n.out_dim(l) + n.out_dim(l);
-      if (i < off + sz) break;
-      off += sz;
-    }
+    const int l = n.layer_of(i);
+    const int64_t off = n.w_off(l);
     const int64_t r = i - off;
     const int in_d = n.in_dim(l), out_d = n.out_dim(l);
     const int inP = (l == 0) ? 16 : WP;
