@@ -6,35 +6,46 @@
   python bench.py [--gpus N --steps K --warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step is the arithmetic of train.py:189-193 (zero_grad, loss_func, backward,
-Adam.step, StepLR.step) on the full batch, with per-iteration logging off.
-Points are sharded across ranks (weak scaling: 2^20 per GPU); one RCCL all-reduce of
-[grad | loss sums] per step.  Rank 0 prints ONE JSON line.
+Both forms run N ranks, one process per GPU.  Under torch.distributed.run the ranks already exist
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment); started plainly with --gpus N > 1 this
+process becomes a LAUNCHER: it never touches the GPU, checks that N devices are visible (refusing
+loudly otherwise — it never reports fewer GPUs than it was asked for), starts the N ranks as child
+processes on 127.0.0.1 and relays rank 0's JSON line.
+
+A step is the arithmetic of train.py:189-193 (zero_grad, loss_func, backward, Adam.step, StepLR.step)
+on the full batch, with per-iteration logging off.  Points are sharded across ranks
+(weak scaling: 2^20 per GPU); ONE RCCL all-reduce of [grad | loss sums] per step (north_star:
+"RCCL all-reduce of the loss gradient over xGMI").  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
-FLOP_PER_POINT = 695_424          # SURVEY §8(d): 6*M*(1+k), M = 29 120, k = 3 (3->8x64->4)
-
 # name: (d_in, d_out, hidden, width, grad_cols, residual, input names, output names, flop/point = 6*M*(1+k))
 WORKLOADS = {
     "ns8x64": (3, 4, 8, 64, (0, 1, 2), "Navier_Stokes", ("t", "x", "y"), ("h", "z", "u", "v"), 695_424),          # BASELINE configs[1]
     "pe8x64": (2, 6, 8, 64, (0, 1), "physics_equation", ("x", "y"), ("h", "U", "V", "eta_mean", "Hrms", "k"), 523_776),  # configs[2], 8x64
     "pe10x10": (2, 6, 10, 10, (0, 1), "physics_equation", ("x", "y"), ("h", "U", "V", "eta_mean", "Hrms", "k"), 17_400),  # configs[2] as written
-    "ns12x256": (3, 4, 12, 256, (0, 1, 2), "Navier_Stokes", ("t", "x", "y"), ("h", "z", "u", "v"), 17_330_688),  # configs[3] shape, fp32
+    "ns12x256": (3, 4, 12, 256, (0, 1, 2), "Navier_Stokes", ("t", "x", "y"), ("h", "z", "u", "v"), 17_330_688),  # configs[3] shape
     "co100x20": (2, 3, 100, 20, (0, 1), "continuity_ftemp", ("x", "y"), ("U", "V", "h"), 6 * (2 * 20 + 99 * 400 + 60) * 3),  # config_CMB_h.json net
 }
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PEAK_BF16_MFMA_TFLOPS = 2516.8    # same guide: dense bf16 MFMA = 16x the fp32 matrix rate (~2.5 PF)
 PTS_PER_GPU = 1 << 20
+# HBM bytes per point from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 on
+# gfx950 + WRITE_SIZE), keyed by (workload, bf16)
+PMC_SUMMARIES = {
+    ("ns8x64", False): ("profiles/r01/fused_v10_pmc_summary.json", "hbm_bytes_per_point"),
+    ("ns12x256", True): ("profiles/r02/wide_bf16_pmc_summary.json", "hbm_bytes_per_point"),
+    ("ns12x256", False): ("profiles/r02/wide_f32_pmc_summary.json", "hbm_bytes_per_point"),
+}
 
 
 def log(msg):
@@ -63,6 +74,7 @@ def usable_cpus() -> int:
 def cpu_baseline(threads: int):
     """Oracle (autograd formulation of the reference, torch CPU) timed on a bounded sample:
     N = 10 000 points (BASELINE configs[0] size), 1 warm-up + steps until ~12 s."""
+    import torch
     from oracle import pinn_oracle as O
     torch.set_num_threads(threads)
     log(f"cpu baseline on {threads} threads")
@@ -90,38 +102,116 @@ def cpu_baseline(threads: int):
                       f"N={N} points x {n} steps, 3->8x64->4 Navier_Stokes, fp32"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=PTS_PER_GPU, help="points per GPU")
-    ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 generic, 2 fused")
+    ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 generic, 2 fused, 3 wide, 4/5 fused tile/coop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bf16", action="store_true", help="bf16 MFMA operands (wide engine only; extra evidence)")
     ap.add_argument("--workload", default="ns8x64", choices=sorted(WORKLOADS),
                     help="default = the headline BASELINE configs[1]; others are extra evidence, not the contract line")
-    args = ap.parse_args()
+    ap.add_argument("--test-evaluator", default=os.environ.get("PINN_BENCH_TEST_EVALUATOR"),
+                    help="module:factory of a CPU evaluator (tests only: rehearses the N-rank launcher and the "
+                         "all-reduce path with gloo on a machine without GPUs; the line it prints is marked invalid)")
+    return ap.parse_args(argv)
 
+
+# ---- launcher: `python bench.py --gpus N` with no torch.distributed.run around it ------------------------------
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv) -> int:
+    """Start args.gpus ranks of this script as child processes and wait for them.  This process makes NO GPU
+    call (torch.cuda.device_count() does not initialise the GPU on this image; the children do)."""
+    n = args.gpus
+    if not args.test_evaluator:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible; refusing to run a smaller job under "
+                  f"that name", file=sys.stderr, flush=True)
+            return 2
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PINN_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this pool
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    log(f"launcher: started {n} ranks on 127.0.0.1:{port} (pids {[p.pid for p in procs]})")
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    log(f"launcher: rank pid {p.pid} exited with {code}; stopping the others")
+                    for q in pending:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, argv))
+
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if world != args.gpus:
+        print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: the job would not be the one named; refusing",
+              file=sys.stderr, flush=True)
+        sys.exit(2)
+    cpu_test = bool(args.test_evaluator)
+    if cpu_test:
+        dev = torch.device("cpu")
+    else:
+        if torch.cuda.device_count() <= local:
+            print(f"bench.py: rank {rank} wants cuda:{local} but {torch.cuda.device_count()} GPU(s) are visible",
+                  file=sys.stderr, flush=True)
+            sys.exit(2)
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     dist = None
     force_dist = os.environ.get("PINN_BENCH_FORCE_DIST") == "1"     # exercise the RCCL path with one rank
     if world > 1 or force_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
-
-    from pinn_depthestimation_amd import Engine, NetDesc, ResidualSpec
-    from pinn_depthestimation_amd.dnn import init_flat_params
+        if cpu_test:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     d_in, d_out, hidden, width, gcols, res_name, in_names, out_names, flop_pt = WORKLOADS[args.workload]
+    from pinn_depthestimation_amd import NetDesc, ResidualSpec
+    from pinn_depthestimation_amd.dnn import init_flat_params
     desc = NetDesc(d_in, d_out, hidden, width, gcols, engine=args.engine, precision=1 if args.bf16 else 0)
     spec = ResidualSpec.from_names(res_name, in_names, desc.grad_cols, out_names)
-    eng = Engine(desc, dev)
+    if cpu_test:
+        import importlib
+        mod, fn = args.test_evaluator.split(":")
+        eng = getattr(importlib.import_module(mod), fn)(desc, spec)
+    else:
+        from pinn_depthestimation_amd import Engine
+        eng = Engine(desc, dev)
     P = desc.n_params
     g = torch.Generator().manual_seed(1234)              # same weights on every rank
     params = init_flat_params(desc.layers, "xavier", g).to(dev)
@@ -139,24 +229,33 @@ def main():
     grad, sums = buf[:P], buf[P:]
     m, v = torch.zeros(P, device=dev), torch.zeros(P, device=dev)
     lr0, gamma, sched_step = 1e-4, 0.8, 10000            # config_CMB.json:11-16
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
+
+    def mk_events():
+        return None if cpu_test else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev = [mk_events() for _ in range(args.steps)]         # around the loss+gradient kernel chain
+    ev_ar = [mk_events() for _ in range(args.steps)]      # around the all-reduce
+    host_ar = [0.0]
 
     def step(i, timed_idx=None):
         grad.zero_()
-        if timed_idx is not None: ev[timed_idx][0].record()
+        timed = timed_idx is not None and not cpu_test
+        if timed: ev[timed_idx][0].record()
         eng.residual_loss_grad(spec, scale, params, X, grad, sums=sums)
-        if timed_idx is not None: ev[timed_idx][1].record()
+        if timed: ev[timed_idx][1].record()
         if dist is not None:
+            if timed: ev_ar[timed_idx][0].record()
+            t_ar = time.perf_counter()
             dist.all_reduce(buf)
+            if timed: ev_ar[timed_idx][1].record()
+            elif timed_idx is not None: host_ar[0] += time.perf_counter() - t_ar
         lr = lr0 * gamma ** (i // sched_step)
         eng.adam_step(params, grad, m, v, i + 1, lr)
 
     def barrier():
-        torch.cuda.synchronize()
+        if not cpu_test: torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not cpu_test: torch.cuda.synchronize()
 
     log(f"rank {rank}/{world}: {N} points, P={P}, engine={args.engine}; warm-up")
     for i in range(args.warmup):
@@ -176,35 +275,45 @@ def main():
     log(f"{args.steps} steps in {dt:.3f} s; loss {loss:.5e}")
 
     if rank == 0:
-        kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-        traffic = None   # HBM bytes per launch from the committed PMC passes of this same command
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "fused_v10_pmc_summary.json")))
-            if args.engine in (0, 2) and args.workload == "ns8x64":
-                traffic = pm["hbm_bytes_per_point"] * N
-        except Exception:
-            pass
-        achieved = N * flop_pt / (kern_ms * 1e-3) / 1e12
+        if cpu_test:
+            kern_ms = None
+            ar_ms = host_ar[0] / args.steps * 1e3 if dist is not None else 0.0
+        else:
+            kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+            ar_ms = sum(a.elapsed_time(b) for a, b in ev_ar) / args.steps if dist is not None else 0.0
+        traffic, traffic_src = None, None   # HBM bytes per launch from the committed PMC passes of this same command
+        src = PMC_SUMMARIES.get((args.workload, bool(args.bf16)))
+        if src is not None and not cpu_test and args.engine in (0, 2, 3):
+            try:
+                pm = json.load(open(os.path.join(ROOT, src[0])))
+                traffic = pm[src[1]] * N
+                traffic_src = f"rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, {src[0]}"
+            except Exception:
+                pass
+        achieved = N * flop_pt / (kern_ms * 1e-3) / 1e12 if kern_ms else None
         peak = PEAK_BF16_MFMA_TFLOPS if args.bf16 else PEAK_F32_MFMA_TFLOPS
+        ms_step = dt / args.steps * 1e3
         out = {
             "metric": "collocation-point residuals/sec (fwd+PDE-grad+Adam)",
             "value": n_global * args.steps / dt, "unit": "residual-points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.bf16 else "f32", "data": "synthetic",
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if args.bf16 else "f32",
+            "data": "synthetic" if not cpu_test else "INVALID: test evaluator on CPU (launcher rehearsal, not a measurement)",
             "config": {"workload": (f"BASELINE configs[1]: " if args.workload == "ns8x64" else f"[{args.workload}] ") +
                                    f"{d_in}->{hidden}x{width} tanh->{d_out} MLP, {res_name} residual, "
                                    f"{N} synthetic ({','.join(in_names)}) points per GPU, full-batch Adam step",
                        "points_per_gpu": N, "global_points": n_global, "params": P,
-                       "parallelism": f"dp{world}", "engine": args.engine, "final_loss": loss},
+                       "parallelism": f"dp{world}", "engine": args.engine, "final_loss": loss,
+                       "allreduce_bytes": (P + nt) * 4 if dist is not None else 0,
+                       "allreduce_ms": ar_ms, "allreduce_frac_of_step": ar_ms / ms_step if ms_step > 0 else 0.0},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
-                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                         "traffic_source": ("rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, "
-                                            "profiles/r01/fused_v10_pmc_summary.json") if traffic is not None else None,
+                         "unit": "TFLOP/s", "frac": achieved / peak if achieved else None, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernel": "pinn_residual_loss_grad (fwd jet + residual + reverse sweep)",
                          "kernel_ms": kern_ms, "flop_per_point": flop_pt},
         }
-        if world == 1 and not args.no_cpu_baseline and args.workload == "ns8x64":
+        if world == 1 and not args.no_cpu_baseline and args.workload == "ns8x64" and not cpu_test:
             out["cpu_baseline"] = cpu_baseline(usable_cpus())
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define PINN_ABI_VERSION 1
+#define PINN_ABI_VERSION 2
 
 #define PINN_MAX_DIRS 3   /* tangent directions (inputs with requires_grad) */
 #define PINN_MAX_ROLES 8
@@ -59,6 +59,11 @@ extern "C" {
 #define PINN_ENGINE_GENERIC 1  /* layer-by-layer VALU kernels, any shape */
 #define PINN_ENGINE_FUSED 2    /* MFMA chain kernel, one persistent launch, hidden width <= 64 */
 #define PINN_ENGINE_WIDE 3     /* MFMA chain, one launch per layer, 64 < hidden width <= 256 */
+/* sub-values of PINN_ENGINE_FUSED: which of its kernels runs (AUTO / FUSED choose by point count).
+ * They are part of the descriptor, not of the process environment: the library reads no
+ * environment variables and keeps no mutable state that changes results. */
+#define PINN_ENGINE_FUSED_TILE 4  /* one wave per 16-point tile (the large-N kernel) */
+#define PINN_ENGINE_FUSED_COOP 5  /* four waves per tile (small point sets; padded hidden width 64 only) */
 
 /* GEMM operand precision.  Everything outside the MFMAs (tanh, residual, adjoints, gradient
  * accumulation, Adam) is fp32 in both modes. */

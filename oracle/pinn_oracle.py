@@ -278,3 +278,31 @@ def lbfgs_trajectory(params, loss_fn, max_iter: int, lr=1.0, max_eval=None, hist
 
     opt.step(closure)
     return losses, [p.detach() for p in params]
+
+
+def scipy_lbfgsb_trajectory(params, loss_fn, options):
+    """The stale l_bfgs_b_optimizer wrapper's contract (bytecode only, never executed):
+    scipy.optimize.minimize(fun, x0, jac=True, method='L-BFGS-B', options=...) over the flattened weights,
+    flat float64 vector <-> fp32 network.  Returns (every evaluated loss, OptimizeResult)."""
+    import numpy as np
+    from scipy.optimize import minimize
+    params = [p.detach().clone().requires_grad_(True) for p in params]
+    sizes = [p.numel() for p in params]
+    evals = []
+
+    def fun(x):
+        off = 0
+        with torch.no_grad():
+            for p, n in zip(params, sizes):
+                p.copy_(torch.from_numpy(x[off:off + n].astype(np.float32)).view_as(p))
+                off += n
+        for p in params:
+            p.grad = None
+        loss = loss_fn(params)
+        loss.backward()
+        evals.append(float(loss.detach()))
+        return float(loss.detach()), torch.cat([p.grad.reshape(-1) for p in params]).numpy().astype(np.float64)
+
+    x0 = torch.cat([p.detach().reshape(-1) for p in params]).numpy().astype(np.float64)
+    res = minimize(fun, x0, jac=True, method="L-BFGS-B", options=options)
+    return evals, res

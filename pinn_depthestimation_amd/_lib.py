@@ -15,6 +15,8 @@ PINN_MAX_ROLES = 8
 
 ACT_TANH, ACT_LEAKY_RELU = 0, 1
 ENGINE_AUTO, ENGINE_GENERIC, ENGINE_FUSED, ENGINE_WIDE = 0, 1, 2, 3
+ENGINE_FUSED_TILE, ENGINE_FUSED_COOP = 4, 5     # sub-values of ENGINE_FUSED: force one of its kernels (pinn_hip.h)
+ABI_VERSION = 2
 PREC_F32, PREC_BF16 = 0, 1
 
 RES_NAVIER_STOKES, RES_PHYSICS_EQUATION, RES_CONTINUITY_FTEMP, RES_CONTINUITY_ONLY = 1, 2, 3, 4
@@ -97,6 +99,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    if lib.pinn_version() != ABI_VERSION:
+        raise PinnError(f"{LIB_PATH} has ABI version {lib.pinn_version()}, this package binds version {ABI_VERSION}: rebuild it")
     _lib = lib
     return lib
 

@@ -176,29 +176,66 @@ def _sliced_cols(src: JetTensor, idx, out) -> Optional[Tuple[int, ...]]:
     return None
 
 
+def _edge_shape(node, idx):
+    """Shape of the tensor an autograd edge (node, output index) carries, or None if torch does not say."""
+    v = getattr(node, "variable", None)
+    if isinstance(v, torch.Tensor):
+        return tuple(v.shape)
+    meta = getattr(node, "_input_metadata", None)
+    try:
+        return tuple(meta[idx].shape)
+    except Exception:
+        return None
+
+
+def _is_cat_of_columns(fn, x: torch.Tensor) -> bool:
+    """Is `fn` the backward node of torch.cat([... (N,1) columns ...], dim=-1) that produced x?
+    Decided STRUCTURALLY, not by the node's class name (a torch internal that may be renamed): the node
+    has exactly one input edge per column of x, and every edge that carries a gradient comes from an
+    (N, 1) tensor.  No other single operation assembles an (N, d_in) matrix from (N, 1) operands — an
+    elementwise op on an (N, d_in) leaf has (N, d_in) operands.  A recorded concatenation axis, where
+    torch exposes one, must be the last."""
+    d_in = x.shape[1]
+    if fn is None or len(fn.next_functions) != d_in:
+        return False
+    dim = getattr(fn, "_saved_dim", None)
+    if dim is not None and dim not in (-1, x.dim() - 1, 2 ** 64 - 1):   # (-1 is stored as an unsigned wrap)
+        return False
+    live = [(n, i) for n, i in fn.next_functions if n is not None]
+    if not live:
+        return False
+    return all(_edge_shape(n, i) == (x.shape[0], 1) for n, i in live)
+
+
+def _leaf_of(node):
+    """The leaf tensor behind an accumulate-grad node (identified by its `.variable`, not its name)."""
+    v = getattr(node, "variable", None)
+    return v if isinstance(v, torch.Tensor) else None
+
+
 def _sniff_sources(model, x: torch.Tensor):
     """Which X columns are differentiated, and which user tensor sits behind each one.
     train.py:86-88,144-148: the inputs are (N,1) tensors joined by torch.cat(dim=-1)."""
     d_in = x.shape[1]
     override = getattr(model, "_grad_cols_override", None)
     fn = x.grad_fn
-    if fn is not None and type(fn).__name__ == "CatBackward0" and len(fn.next_functions) == d_in:
+    if _is_cat_of_columns(fn, x):
         cols, sources = [], []
         for i, (node, _) in enumerate(fn.next_functions):
             if node is None:
                 continue
             cols.append(i)
-            if type(node).__name__ == "AccumulateGrad":
-                sources.append(("leaf", node.variable))
-            else:
-                sources.append(("node", node))
+            leaf = _leaf_of(node)
+            sources.append(("leaf", leaf) if leaf is not None else ("node", node))
         if override is not None and tuple(cols) != tuple(override):
             raise PinnError(f"set_grad_columns({override}) disagrees with the inputs' requires_grad ({cols})")
         return tuple(cols), sources
     if override is not None:
         return tuple(override), [None] * len(override)
     if x.is_leaf and d_in <= 3:
-        return tuple(range(d_in)), [None] * d_in       # whole-matrix leaf: every column differentiated
+        # test.py:62-76 style: ONE leaf matrix with requires_grad — every column is a differentiated input
+        # (3 = the engine's PINN_MAX_DIRS); wider leaf matrices must name their columns
+        return tuple(range(d_in)), [None] * d_in
     raise PinnError(
         "cannot tell which input columns are differentiated: build the input with "
         "torch.cat([... (N,1) columns ...], dim=-1) as train.py:148 does, or call "

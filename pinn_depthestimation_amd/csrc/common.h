@@ -11,8 +11,10 @@ namespace pinn {
 void set_error(const char* fmt, ...);
 
 // layer geometry helpers: layers = [d_in] + [width]*n_hidden + [d_out] (train.py:56)
+constexpr int FUSED_KERNEL_AUTO = 0, FUSED_KERNEL_TILE = 1, FUSED_KERNEL_COOP = 2;
 struct Net {
   int d_in, d_out, L /*hidden layers*/, W, k, K1, act, prec;
+  int fused_kernel;  // FUSED_KERNEL_*: which fused kernel desc.engine asked for (PINN_ENGINE_FUSED_TILE / _COOP)
   int dir_col[PINN_MAX_DIRS];
   int n_lin;  // L + 1 linear layers
   __host__ __device__ int in_dim(int l) const { return l == 0 ? d_in : W; }
@@ -59,7 +61,7 @@ int generic_loss(const Net& n, const LossReq& rq, const float* params, const flo
                  void* ws, int64_t ws_bytes, hipStream_t s);
 
 // fused MFMA engine (pinn_fused.hip)
-bool fused_supports(const Net& n);
+bool fused_supports(const Net& n, bool want_grad);
 int64_t fused_workspace_bytes(const Net& n, int64_t N);
 int fused_forward(const Net& n, const float* params, const float* X, int64_t N, float* Y, float* dY,
                   void* ws, int64_t ws_bytes, hipStream_t s);
@@ -73,6 +75,11 @@ int wide_forward(const Net& n, const float* params, const float* X, int64_t N, f
                  void* ws, int64_t ws_bytes, hipStream_t s);
 int wide_loss(const Net& n, const LossReq& rq, const float* params, const float* X, int64_t N,
               void* ws, int64_t ws_bytes, hipStream_t s);
+
+// compute units of the CURRENT device (cached per device ordinal: one process may drive several GPUs)
+int device_cu_count();
+// raise a kernel's dynamic-LDS limit above 64 KB, once per (kernel, device) instead of on every launch
+int ensure_dynamic_lds(const void* kernel, size_t lds_bytes);
 
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();

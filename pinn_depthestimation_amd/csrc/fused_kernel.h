@@ -53,9 +53,6 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #ifndef PINN_FUSED_XPREF
 #define PINN_FUSED_XPREF 1   // 1: request the next tile's input coordinates one tile ahead
 #endif
-#ifndef PINN_FUSED_STREAM
-#define PINN_FUSED_STREAM 1   // streamed weights + copy-free layer loops (v6); 0 = the v5 prefetch structure
-#endif
 constexpr int FUSED_WAVES = PINN_FUSED_WAVES;
 constexpr int FUSED_THREADS = FUSED_WAVES * 64;
 constexpr int TB_FLOATS = 256;                // one 16x16 fp32 block, XOR-swizzled (see transpose_write)
@@ -87,7 +84,7 @@ struct FusedParams {
   const float* mse_scale;    // mse: device column scales
   float* wg_sums;            // [grid][MAX_SUMS]
   float* wg_grads;           // [grid][PP]: acc_lds: written once at kernel end; else the workgroups' live global copies
-  int acc_lds, nrep;         // (nrep: unused since the global-atomic path went; kept so the struct layout is unchanged)
+  int acc_lds;               // 1: the workgroup's gradient copy lives in LDS
   int PW, PB;                // padded weight / bias float counts
   int lds_acc_floats;        // floats reserved for the LDS gradient copy (0 if unused)
 };
@@ -183,13 +180,6 @@ __device__ __forceinline__ void copy_tiles(f4 (&d)[K1][NT], const f4 (&srcv)[K1]
   for (int c = 0; c < K1; ++c)
 #pragma unroll
     for (int MT = 0; MT < NT; ++MT) d[c][MT] = srcv[c][MT];
-}
-template <int A, int B>
-__device__ __forceinline__ void copy_w(f4 (&d)[A][B], const f4 (&srcv)[A][B]) {
-#pragma unroll
-  for (int i = 0; i < A; ++i)
-#pragma unroll
-    for (int j = 0; j < B; ++j) d[i][j] = srcv[i][j];
 }
 
 template <int NT, int K1>
@@ -773,7 +763,6 @@ __global__ __launch_bounds__(FUSED_THREADS, WP == 16 ? PINN_FUSED_W16_WAVES : FU
     };
     f4 b0[K1][1];
     input_jet(b0);
-#if PINN_FUSED_STREAM
     // ---- forward chain: weights streamed block-by-block (gemm_stream), activations written straight
     // into the next GEMM's B operand: nothing is copied between layers ------------------------------
     f4 a[K1][NTH];
@@ -888,92 +877,6 @@ __global__ __launch_bounds__(FUSED_THREADS, WP == 16 ? PINN_FUSED_W16_WAVES : FU
         weight_grad<NTH, 1, K1>(sink, 0, 0, P.PW + b_off_p<WP>(0), z, b1, tb, lane);
       }
     }
-#else
-    // ---- forward chain (weights of layer l+1 are fetched while layer l computes) -------------
-    f4 w0[NTH][1];
-    load_w<1, NTH>(Wp_, w0, p, q);
-    f4 wh[NTH][NTH];
-    load_w<NTH, NTH>(Wp_ + w_off_p<WP>(L > 1 ? 1 : 0), wh, p, q);      // L == 1: dummy in-bounds read, unused
-    f4 wl[1][NTH];
-    load_w<NTH, 1>(Wp_ + w_off_p<WP>(L), wl, p, q);
-    f4 a[K1][NTH];
-    init_bias<NTH, K1>(Bp_ + b_off_p<WP>(0), a, q);
-    gemm_chain<1, NTH, K1>(w0, b0, a);
-    PINN_STAMP(0);
-    activate<ACT, NTH, K1>(a);
-    if (GRAD && L > 1) spill<NTH, K1>(scr, a, lane);      // a_L itself stays in registers for the reverse sweep
-    PINN_STAMP(1);
-    for (int l = 1; l < L; ++l) {
-      f4 wn[NTH][NTH];
-      load_w<NTH, NTH>(Wp_ + w_off_p<WP>(l + 1 < L ? l + 1 : l), wn, p, q);   // prefetch (last: redundant, in bounds)
-      f4 nx[K1][NTH];
-      init_bias<NTH, K1>(Bp_ + b_off_p<WP>(l), nx, q);
-      gemm_chain<NTH, NTH, K1>(wh, a, nx);
-      PINN_STAMP(0);
-      activate<ACT, NTH, K1>(nx);
-      if (GRAD && l < L - 1) spill<NTH, K1>(scr + l * SLOT, nx, lane);   // (the last hidden jet is never re-read)
-      PINN_STAMP(1);
-      copy_tiles<NTH, K1>(a, nx);
-      copy_w<NTH, NTH>(wh, wn);
-    }
-    f4 out[K1][1];
-    init_bias<1, K1>(Bp_ + b_off_p<WP>(L), out, q);
-    gemm_chain<NTH, 1, K1>(wl, a, out);
-    // reverse-sweep operands whose latency the residual evaluation below hides
-    f4 wtl[NTH][1];
-    f4 wt[NTH][NTH];
-    f4 ai[K1][NTH];
-    if constexpr (GRAD) {
-      load_w<1, NTH>(WTp_ + w_off_p<WP>(L), wtl, p, q);
-      load_w<NTH, NTH>(WTp_ + w_off_p<WP>(L > 1 ? L - 1 : 0), wt, p, q);
-      unspill<NTH, K1>(scr + (L > 1 ? L - 2 : 0) * SLOT, ai, lane);            // a_{L-1}
-    }
-
-    // ---- outputs / loss -----------------------------------------------------------------------
-    f4 G[K1][1];
-    loss_epilogue<K1, GRAD, (WP < 64), EPI>(P, out, G, sums, sm, sm_mse, tb, pt, ptc, valid, p, q);
-
-    PINN_STAMP(2);
-    // ---- reverse sweep ------------------------------------------------------------------------
-    // Each spilled layer a_l is read ONCE (as the input of layer l's weight gradient, then kept as
-    // the output whose activation adjoint layer l-1 needs), and a_{l-1} / W_{l-1}^T are fetched
-    // while layer l's back-propagation GEMM runs.  `a` still holds a_L from the forward chain.
-    if constexpr (GRAD) {
-      // output layer L (linear): zbar = G; input = a_L
-      weight_grad<1, NTH, K1>(sink, L, w_off_p<WP>(L), P.PW + b_off_p<WP>(L), G, a, tb, lane);
-      f4 g[K1][NTH];
-      zero_tiles<NTH, K1>(g);
-      gemm_chain<1, NTH, K1>(wtl, G, g);
-      f4 ao[K1][NTH];
-      copy_tiles<NTH, K1>(ao, a);
-      for (int l = L - 1; l >= 1; --l) {
-        // hidden layer l: output a_{l+1} (= ao), input a_l (= ai), W_l^T (= wt)
-        PINN_STAMP(3);
-        activate_adjoint<ACT, NTH, K1>(g, ao);
-        PINN_STAMP(4);
-        weight_grad<NTH, NTH, K1>(sink, l, w_off_p<WP>(l), P.PW + b_off_p<WP>(l), g, ai, tb, lane);
-        PINN_STAMP(5);
-        f4 an[K1][NTH];
-        f4 wtn[NTH][NTH];
-        unspill<NTH, K1>(scr + (l >= 2 ? l - 2 : 0) * SLOT, an, lane);            // a_{l-1} for the next iteration
-        load_w<NTH, NTH>(WTp_ + w_off_p<WP>(l >= 2 ? l - 1 : 1), wtn, p, q);
-        f4 g2[K1][NTH];
-        zero_tiles<NTH, K1>(g2);
-        gemm_chain<NTH, NTH, K1>(wt, g, g2);
-        PINN_STAMP(6);
-        copy_tiles<NTH, K1>(g, g2);
-        copy_tiles<NTH, K1>(ao, ai);
-        copy_tiles<NTH, K1>(ai, an);
-        copy_w<NTH, NTH>(wt, wtn);
-      }
-      {  // layer 0: output a_1 (= ao), input = (x, unit tangents)
-        activate_adjoint<ACT, NTH, K1>(g, ao);
-        f4 b1[K1][1];
-        input_jet(b1);   // recomputed rather than kept live across the whole tile
-        weight_grad<NTH, 1, K1>(sink, 0, 0, P.PW + b_off_p<WP>(0), g, b1, tb, lane);
-      }
-    }
-#endif
     PINN_STAMP(7);
   }
 #ifdef PINN_DIAG

@@ -1,6 +1,9 @@
 // pinn_abi.hip — extern "C" entry points of libpinn_hip.so (see include/pinn_hip.h)
 // and the engine dispatch.  No torch types, no exceptions, no allocation.
 #include <string.h>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include "common.h"
 
 namespace pinn {
@@ -12,6 +15,45 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// The only process-wide state of the library: immutable facts about devices / kernels, filled on first use.
+namespace {
+std::mutex g_cache_mu;
+constexpr int MAX_DEVICES = 64;
+int g_cus[MAX_DEVICES];                                              // 0 = not yet asked
+struct LdsKey { const void* fn; int dev; size_t bytes; };
+std::vector<LdsKey> g_lds_set;
+}  // namespace
+
+int device_cu_count() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return 256;
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  if (g_cus[dev] == 0) {
+    int v = 0;
+    g_cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  return g_cus[dev];
+}
+
+int ensure_dynamic_lds(const void* kernel, size_t lds_bytes) {
+  if (lds_bytes <= 64 * 1024) return PINN_OK;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { set_error("hipGetDevice failed"); return PINN_ERR_LAUNCH; }
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  for (LdsKey& k : g_lds_set)
+    if (k.fn == kernel && k.dev == dev) {
+      if (k.bytes >= lds_bytes) return PINN_OK;
+      hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds_bytes, hipGetErrorString(e)); return PINN_ERR_LAUNCH; }
+      k.bytes = lds_bytes;
+      return PINN_OK;
+    }
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds_bytes, hipGetErrorString(e)); return PINN_ERR_LAUNCH; }
+  g_lds_set.push_back(LdsKey{kernel, dev, lds_bytes});
+  return PINN_OK;
 }
 
 int make_net(const pinn_desc* d, Net* n) {
@@ -32,6 +74,9 @@ int make_net(const pinn_desc* d, Net* n) {
     set_error("invalid precision %d", d->precision); return PINN_ERR_INVALID;
   }
   n->prec = d->precision;
+  if (d->engine < PINN_ENGINE_AUTO || d->engine > PINN_ENGINE_FUSED_COOP) { set_error("invalid engine %d", d->engine); return PINN_ERR_INVALID; }
+  n->fused_kernel = d->engine == PINN_ENGINE_FUSED_TILE ? FUSED_KERNEL_TILE
+                  : d->engine == PINN_ENGINE_FUSED_COOP ? FUSED_KERNEL_COOP : FUSED_KERNEL_AUTO;
   for (int j = 0; j < PINN_MAX_DIRS; ++j) {
     n->dir_col[j] = j < d->k ? d->dir_col[j] : -1;
     if (j < d->k && (d->dir_col[j] < 0 || d->dir_col[j] >= d->d_in)) {
@@ -43,26 +88,27 @@ int make_net(const pinn_desc* d, Net* n) {
 }
 
 // 1 = generic, 2 = fused, 3 = wide
-static int pick_engine(const pinn_desc* d, const Net& n, int* rc) {
+static int pick_engine(const pinn_desc* d, const Net& n, bool want_grad, int* rc) {
   *rc = PINN_OK;
+  const int asked = (d->engine == PINN_ENGINE_FUSED_TILE || d->engine == PINN_ENGINE_FUSED_COOP) ? PINN_ENGINE_FUSED : d->engine;
   if (n.prec == PINN_PREC_BF16) {   // bf16 operands exist on the wide engine only
-    if ((d->engine != PINN_ENGINE_AUTO && d->engine != PINN_ENGINE_WIDE) || !wide_supports(n)) {
+    if ((asked != PINN_ENGINE_AUTO && asked != PINN_ENGINE_WIDE) || !wide_supports(n)) {
       set_error("precision bf16 is implemented on the wide engine (64 < width <= 256, tanh, k in {0,2,3}) only");
       *rc = PINN_ERR_UNSUPPORTED;
     }
     return PINN_ENGINE_WIDE;
   }
-  if (d->engine == PINN_ENGINE_GENERIC) return PINN_ENGINE_GENERIC;
-  if (d->engine == PINN_ENGINE_FUSED || d->engine == PINN_ENGINE_WIDE) {
-    const bool ok = d->engine == PINN_ENGINE_FUSED ? fused_supports(n) : wide_supports(n);
+  if (asked == PINN_ENGINE_GENERIC) return PINN_ENGINE_GENERIC;
+  if (asked == PINN_ENGINE_FUSED || asked == PINN_ENGINE_WIDE) {
+    const bool ok = asked == PINN_ENGINE_FUSED ? fused_supports(n, want_grad) : wide_supports(n);
     if (!ok) {
-      set_error("%s engine does not support this shape (width %d, d_in %d, d_out %d, k %d, act %d)",
-                d->engine == PINN_ENGINE_FUSED ? "fused" : "wide", n.W, n.d_in, n.d_out, n.k, n.act);
+      set_error("%s engine does not support this request (width %d, d_in %d, d_out %d, k %d, act %d, gradient %d)",
+                asked == PINN_ENGINE_FUSED ? "fused" : "wide", n.W, n.d_in, n.d_out, n.k, n.act, (int)want_grad);
       *rc = PINN_ERR_UNSUPPORTED;
     }
-    return d->engine;
+    return asked;
   }
-  if (fused_supports(n)) return PINN_ENGINE_FUSED;
+  if (fused_supports(n, want_grad)) return PINN_ENGINE_FUSED;
   if (wide_supports(n)) return PINN_ENGINE_WIDE;
   return PINN_ENGINE_GENERIC;
 }
@@ -139,10 +185,17 @@ int32_t pinn_param_count(const pinn_desc* desc, int64_t* count) {
 int32_t pinn_query_workspace(const pinn_desc* desc, int64_t N, int64_t* bytes) {
   Net n; int rc = make_net(desc, &n); if (rc) return rc;
   if (!bytes || N < 0) { set_error("bad arguments"); return PINN_ERR_INVALID; }
-  const int e = pick_engine(desc, n, &rc); if (rc) return rc;
-  // one workspace must serve every call on this network, including plain (k = 0) forwards
-  int64_t b = e == PINN_ENGINE_FUSED ? fused_workspace_bytes(n, N)
-            : e == PINN_ENGINE_WIDE ? wide_workspace_bytes(n, N) : generic_workspace_bytes(n, N);
+  // one workspace must serve every call on this network: plain (k = 0) forwards, and gradient calls
+  // that AUTO routes to another engine than the forward (k = 1 networks: fused forward, generic gradient)
+  auto ws_of = [&](int e) {
+    return e == PINN_ENGINE_FUSED ? fused_workspace_bytes(n, N)
+         : e == PINN_ENGINE_WIDE ? wide_workspace_bytes(n, N) : generic_workspace_bytes(n, N);
+  };
+  const int e = pick_engine(desc, n, false, &rc); if (rc) return rc;
+  int64_t b = ws_of(e);
+  int rc2 = PINN_OK;
+  const int eg = pick_engine(desc, n, true, &rc2);
+  if (rc2 == PINN_OK && eg != e) { const int64_t bg = ws_of(eg); if (bg > b) b = bg; }
   if (b < 0) { set_error("network not supported"); return PINN_ERR_UNSUPPORTED; }
   *bytes = b;
   return PINN_OK;
@@ -155,7 +208,7 @@ static int32_t forward_impl(const pinn_desc* desc, const float* params, const fl
   if (N == 0) return PINN_OK;
   if (!jet) { n.k = 0; n.K1 = 1; dY = nullptr; }
   if (jet && n.k == 0) { set_error("forward_jet needs k >= 1"); return PINN_ERR_INVALID; }
-  const int e = pick_engine(desc, n, &rc); if (rc) return rc;
+  const int e = pick_engine(desc, n, false, &rc); if (rc) return rc;
   return e == PINN_ENGINE_FUSED ? fused_forward(n, params, X, N, Y, dY, ws, ws_bytes, (hipStream_t)stream)
        : e == PINN_ENGINE_WIDE ? wide_forward(n, params, X, N, Y, dY, ws, ws_bytes, (hipStream_t)stream)
                                : generic_forward(n, params, X, N, Y, dY, ws, ws_bytes, (hipStream_t)stream);
@@ -193,7 +246,7 @@ static int32_t residual_impl(const pinn_desc* desc, const pinn_residual_spec* sp
   rq.kind = 0; rq.n_split = -1; rq.spec = *spec; rq.scale = term_scale; rq.sums = term_sums;
   rq.grad = want_grad ? grad_flat : nullptr; rq.n_terms = residual_terms(spec->residual_id);
   if (N == 0) { (void)hipMemsetAsync(term_sums, 0, rq.n_terms * sizeof(float), (hipStream_t)stream); return PINN_OK; }
-  const int e = pick_engine(desc, n, &rc); if (rc) return rc;
+  const int e = pick_engine(desc, n, want_grad, &rc); if (rc) return rc;
   return e == PINN_ENGINE_FUSED ? fused_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream)
        : e == PINN_ENGINE_WIDE ? wide_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream)
                                : generic_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream);
@@ -226,7 +279,7 @@ int32_t pinn_mse_loss_grad(const pinn_desc* desc, const float* params, const flo
   }
   if (N == 0) { (void)hipMemsetAsync(col_sums, 0, n_cols * sizeof(float), (hipStream_t)stream); return PINN_OK; }
   n.k = 0; n.K1 = 1;  // the fidelity term needs no input derivatives
-  const int e = pick_engine(desc, n, &rc); if (rc) return rc;
+  const int e = pick_engine(desc, n, grad_flat != nullptr, &rc); if (rc) return rc;
   return e == PINN_ENGINE_FUSED ? fused_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream)
        : e == PINN_ENGINE_WIDE ? wide_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream)
                                : generic_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream);
@@ -260,7 +313,7 @@ static int32_t residual_mse_impl(int64_t n_split, const pinn_desc* desc, const p
     rq.kind = 0; rq.n_split = -1;
     (void)hipMemsetAsync(col_sums, 0, n_cols * sizeof(float), (hipStream_t)stream);
   }
-  const int e = pick_engine(desc, n, &rc); if (rc) return rc;
+  const int e = pick_engine(desc, n, true, &rc); if (rc) return rc;
   return e == PINN_ENGINE_FUSED ? fused_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream)
        : e == PINN_ENGINE_WIDE ? wide_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream)
                                : generic_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream);

@@ -1,8 +1,6 @@
 // pinn_fused.hip — host side of the fused MFMA engine: weight packing, workspace carve,
 // launch geometry, cross-workgroup reductions.  Kernel: fused_kernel.h.
 #include <type_traits>
-#include <stdlib.h>
-#include "fused_pair_kernel.h"
 #include "fused_coop_kernel.h"
 
 namespace pinn {
@@ -25,55 +23,23 @@ Geo geo_of(const Net& n) {
   return g;
 }
 
-int cu_count() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    else cus = 256;
-  }
-  return cus;
-}
+int cu_count() { return device_cu_count(); }   // of the CURRENT device (common.h: cached per device)
 
 constexpr int64_t LDS_LIMIT = 160 * 1024;
-#ifndef PINN_NREP
-#define PINN_NREP 16
-#endif
-constexpr int NREP = PINN_NREP;
-#ifndef PINN_FUSED_PAIR_DEFAULT
-#define PINN_FUSED_PAIR_DEFAULT 0
-#endif   // replicated global accumulators when the gradient does not fit LDS
 
 int64_t lds_fixed_bytes() { return (int64_t)(MAX_LOCKS + FUSED_WAVES * TB_PER_WAVE * TB_FLOATS + FUSED_WAVES * MAX_SUMS) * 4; }
 bool fits_lds(const Geo& g) { return (int64_t)g.PP * 4 + lds_fixed_bytes() <= LDS_LIMIT; }
 
-// two-waves-per-SIMD variant (fused_pair_kernel.h): width 64, even jets; PINN_FUSED_PAIR=0/1 overrides
-int64_t pair_lds_fixed_bytes() { return (int64_t)(MAX_LOCKS + PR_WAVES * PR_TB_PER_WAVE * TB_FLOATS + PR_WAVES * MAX_SUMS) * 4; }
-bool pair_default() {   // read per call (the tests flip it)
-  const char* e = getenv("PINN_FUSED_PAIR");
-  return e ? (atoi(e) != 0) : (PINN_FUSED_PAIR_DEFAULT != 0);
-}
-bool use_pair(const Net& n, const Geo& g, bool grad, bool split = false) {
-  if (split) return false;   // the paired kernel's epilogue has no split mode
-  if (g.WP != 64 || (n.K1 != 2 && n.K1 != 4)) return false;
-  if (grad && (int64_t)g.PP * 4 + pair_lds_fixed_bytes() > LDS_LIMIT) return false;
-  if (grad && n.K1 == 2) return true;   // k_fused has no K1 = 2 gradient kernel
-  return pair_default();
-}
-
 // cooperative (four waves per tile) kernel for small point sets (fused_coop_kernel.h): one workgroup
 // per CU runs a tile in ~45 us against ~110 us for k_fused's one-wave tile, so it wins while there is
 // at most one tile per CU (measured: loss+grad 127 -> 69 us at N = 243, 137 -> 93 us at N = 4096,
-// break-even at N = 8192).  PINN_FUSED_COOP=0/1 overrides.
+// break-even at N = 8192).  desc.engine = PINN_ENGINE_FUSED_TILE / _COOP forces one of the two (Net::fused_kernel).
 int64_t coop_lds_bytes(const Net& n, const Geo& g, bool grad) {
   return ((int64_t)(grad ? g.PP : 0) + 2 * (int64_t)n.K1 * 4 * TB_FLOATS + MAX_SUMS) * 4;
 }
 bool use_coop(const Net& n, const Geo& g, bool grad, int64_t N) {
-  const char* e = getenv("PINN_FUSED_COOP");   // read per call: the tests flip it to cover both kernels
-  const int forced = e ? (atoi(e) != 0) : -1;
+  const int forced = n.fused_kernel == FUSED_KERNEL_COOP ? 1 : (n.fused_kernel == FUSED_KERNEL_TILE ? 0 : -1);
   if (forced == 0 || g.WP != 64) return false;
-  if (grad ? (n.K1 == 2) : false) return false;
   if (coop_lds_bytes(n, g, grad) > LDS_LIMIT) return false;
   if (forced == 1) return true;
   return (N + 15) / 16 <= (int64_t)cu_count();
@@ -213,7 +179,6 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
   P.wg_grads = (float*)(base + w.wg_grads);
   P.PW = g.PW; P.PB = g.PB;
   P.acc_lds = (grad && fits_lds(g)) ? 1 : 0;
-  P.nrep = NREP;
   P.lds_acc_floats = P.acc_lds ? g.PP : 0;
   if (rq) {
     P.loss_kind = rq->kind == 0 ? 1 : (rq->kind == 1 ? 2 : 3);
@@ -233,19 +198,11 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
     }
   }
   const bool coop = use_coop(n, g, grad, N);
-  const bool pair = !coop && use_pair(n, g, grad, rq && rq->n_split >= 0);
   if (coop) {
     P.acc_lds = grad ? 1 : 0;
     P.lds_acc_floats = grad ? g.PP : 0;
   }
-  if (pair) {
-    P.n_tiles = (N + 7) / 8;
-    P.scratch_per_wave = (int64_t)n.L * (n.K1 / 2) * g.NTH * 256;
-    P.acc_lds = grad ? 1 : 0;
-    P.lds_acc_floats = grad ? g.PP : 0;
-  }
-  const size_t lds = coop ? (size_t)coop_lds_bytes(n, g, grad)
-                          : (size_t)P.lds_acc_floats * 4 + (size_t)(pair ? pair_lds_fixed_bytes() : lds_fixed_bytes());
+  const size_t lds = coop ? (size_t)coop_lds_bytes(n, g, grad) : (size_t)P.lds_acc_floats * 4 + (size_t)lds_fixed_bytes();
   // 8x64 gradient kernels fill the register file and most of LDS (1 workgroup per CU); the narrow
   // networks' kernels fit 2 waves per SIMD, which hides their per-layer latencies
   const bool one_per_cu = grad && P.acc_lds && !(g.WP <= 32 && 2 * (int64_t)lds <= LDS_LIMIT);
@@ -253,10 +210,6 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
   if (coop) {   // one workgroup per tile, at most one per CU (gradient kernels fill the LDS)
     const int64_t cap = (int64_t)cu_count() * (grad ? 1 : 2);
     grid = (int)(P.n_tiles < cap ? (P.n_tiles < 1 ? 1 : P.n_tiles) : cap);
-  }
-  if (pair) {   // one 8-wave workgroup per CU, 8 points per wave-tile
-    const int64_t want = (P.n_tiles + PR_WAVES - 1) / PR_WAVES;
-    grid = (int)(want < cu_count() ? (want < 1 ? 1 : want) : cu_count());
   }
 
   const int packN = g.PW > g.PB ? g.PW : g.PB;
@@ -269,7 +222,6 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
   }
   int rc;
   if (coop) rc = launch_fused_coop(n.K1, grad, P, grid, lds, s);
-  else if (pair) rc = launch_fused_pair(n.K1, grad, P, grid, lds, s);
   else switch (g.WP) {
     case 16: rc = launch_fused<16>(n.K1, grad, P, grid, lds, s); break;
     case 32: rc = launch_fused<32>(n.K1, grad, P, grid, lds, s); break;
@@ -295,13 +247,15 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
 
 }  // namespace
 
-bool fused_supports(const Net& n) {
+bool fused_supports(const Net& n, bool want_grad) {
   if (n.L + 1 > MAX_LOCKS) return false;
+  if (want_grad && n.K1 == 2) return false;   // no k = 1 gradient kernels (no residual of the reference has one direction)
+  if (n.fused_kernel == FUSED_KERNEL_COOP && padded_width(n.W) != 64) return false;
   return n.W <= 64 && n.d_in <= 16 && n.d_out <= 16 && n.L >= 1 && n.K1 >= 1 && n.K1 <= 4;
 }
 
 int64_t fused_workspace_bytes(const Net& n, int64_t N) {
-  if (!fused_supports(n)) return -1;
+  if (!fused_supports(n, false)) return -1;
   return ws_layout(n, geo_of(n), N > 0 ? N : 1).total;
 }
 
@@ -330,9 +284,7 @@ int fused_loss(const Net& n, const LossReq& rq, const float* params, const float
       return fused_loss(n1, r1, params, X + rq.n_split * n.d_in, N - rq.n_split, ws, ws_bytes, s);
     }
   }
-  if (grad && n.K1 == 2 && !use_pair(n, geo_of(n), true)) {
-    set_error("fused gradient kernels for K1 = 2 exist at hidden width 33..64 only"); return PINN_ERR_UNSUPPORTED;
-  }
+  if (!fused_supports(n, grad)) { set_error("fused engine: no kernel for this request (k = %d, gradient %d)", n.k, (int)grad); return PINN_ERR_UNSUPPORTED; }
   return run(n, grad, &rq, params, X, N, nullptr, nullptr, ws, ws_bytes, s);
 }
 

@@ -8,10 +8,7 @@ namespace pinn {
 template <int K1, bool GRAD, int ACT>
 static int launch_coop_act(const FusedParams& P, int grid, size_t lds, hipStream_t s) {
   auto kern = k_fused_coop<K1, GRAD, ACT>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e)); return PINN_ERR_LAUNCH; }
-  }
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(COOP_THREADS), lds, s, P);
   return check_launch("fused cooperative kernel");
 }
@@ -20,10 +17,7 @@ static int launch_coop_act(const FusedParams& P, int grid, size_t lds, hipStream
 template <int K1, int EPI>
 static int launch_coop_special(const FusedParams& P, int grid, size_t lds, hipStream_t s) {
   auto kern = k_fused_coop<K1, true, PINN_ACT_TANH, EPI>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e)); return PINN_ERR_LAUNCH; }
-  }
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(COOP_THREADS), lds, s, P);
   return check_launch("fused cooperative kernel (specialised epilogue)");
 }

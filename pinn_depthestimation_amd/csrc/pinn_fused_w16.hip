@@ -7,10 +7,7 @@ namespace pinn {
 template <int K1, bool GRAD, bool LDSACC, int ACT>
 static int launch_one_act(const FusedParams& P, int grid, size_t lds, hipStream_t s) {
   auto kern = k_fused<16, K1, GRAD, LDSACC, ACT>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e)); return PINN_ERR_LAUNCH; }
-  }
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(FUSED_THREADS), lds, s, P);
   return check_launch("fused kernel (WP=16)");
 }

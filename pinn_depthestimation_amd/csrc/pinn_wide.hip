@@ -19,15 +19,7 @@ WGeo wgeo(const Net& n) {
 }
 int64_t al256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 
-int cus() {
-  static int c = 0;
-  if (c == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) c = v;
-    else c = 256;
-  }
-  return c;
-}
+int cus() { return device_cu_count(); }
 
 constexpr int64_t ACT_BUDGET_BYTES = (int64_t)6 << 30;   // activation workspace per chunk
 

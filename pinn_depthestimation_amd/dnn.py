@@ -37,7 +37,9 @@ def init_flat_params(layers: Sequence[int], init_type: str = "xavier", generator
         if init_type == "xavier":
             bound = math.sqrt(6.0 / (fan_in + fan_out))
         else:
-            bound = math.sqrt(2.0 / (1 + 0.01 ** 2)) * math.sqrt(3.0 / fan_in)
+            # kaiming_uniform_(w, nonlinearity='leaky_relu') leaves a at its default 0: gain sqrt(2/(1+0^2))
+            # (dnn.py:45 — NOT the 0.01 slope of the LeakyReLU it then applies)
+            bound = math.sqrt(2.0) * math.sqrt(3.0 / fan_in)
         parts.append(torch.empty(fan_out * fan_in).uniform_(-bound, bound, generator=generator))
         if i < n_lin - 1:
             parts.append(torch.zeros(fan_out))

@@ -13,7 +13,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import (ACT_LEAKY_RELU, ACT_TANH, ENGINE_AUTO, ENGINE_FUSED, ENGINE_GENERIC, ENGINE_WIDE, RES_CONTINUITY_FTEMP,
+from ._lib import (ACT_LEAKY_RELU, ACT_TANH, ENGINE_AUTO, ENGINE_FUSED, ENGINE_FUSED_COOP, ENGINE_FUSED_TILE, ENGINE_GENERIC,
+                   ENGINE_WIDE, RES_CONTINUITY_FTEMP,
                    RES_CONTINUITY_ONLY, RES_NAVIER_STOKES, RES_PHYSICS_EQUATION, RES_TERMS, PinnDesc, PinnError,
                    PinnResidualSpec, check)
 
@@ -72,10 +73,10 @@ class NetDesc:
         return d
 
     @staticmethod
-    def from_layers(layers: Sequence[int], grad_cols=(), activation=ACT_TANH, engine=ENGINE_AUTO) -> "NetDesc":
+    def from_layers(layers: Sequence[int], grad_cols=(), activation=ACT_TANH, engine=ENGINE_AUTO, precision=0) -> "NetDesc":
         if len(layers) < 3 or len(set(layers[1:-1])) != 1:
             raise PinnError(f"layers {list(layers)} are not [d_in] + [width]*n + [d_out] (train.py:56)")
-        return NetDesc(layers[0], layers[-1], len(layers) - 2, layers[1], tuple(grad_cols), activation, engine)
+        return NetDesc(layers[0], layers[-1], len(layers) - 2, layers[1], tuple(grad_cols), activation, engine, precision)
 
 
 @dataclass(frozen=True)
@@ -153,6 +154,7 @@ class Engine:
         self.device = torch.device(device)
         self._cdesc: Dict[Tuple[int, int], PinnDesc] = {}
         self._ws: Dict[int, torch.Tensor] = {}
+        self._ws_need: Dict[Tuple[int, int], int] = {}
         cnt = C.c_int64()
         check(self.lib.pinn_param_count(C.byref(desc.c_struct()), C.byref(cnt)), "pinn_param_count")
         self.n_params = cnt.value
@@ -164,110 +166,132 @@ class Engine:
             self._cdesc[e] = self.desc.with_(engine=e).c_struct()
         return self._cdesc[e]
 
+    def _chk(self, t: torch.Tensor, name: str, shape=None):
+        _chk(t, name, shape)
+        if t.device.index != self._index():
+            raise PinnError(f"{name} lives on {t.device} but this engine is bound to {self.device}")
+
+    def _index(self) -> int:
+        """Ordinal of this engine's GPU ("cuda" without an index binds to the device current at first use)."""
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        return self.device.index
+
+    def _run(self, what: str, fn, *args):
+        """Call one C-ABI entry point on THIS engine's device and on that device's current stream
+        (appended as the last argument), whatever device the calling thread has current: launch
+        geometry (CU count) and the stream both belong to the device the tensors live on."""
+        idx = self._index()
+        if torch.cuda.current_device() != idx:
+            with torch.cuda.device(idx):
+                check(fn(*args, C.c_void_p(torch.cuda.current_stream(idx).cuda_stream)), what)
+        else:
+            check(fn(*args, C.c_void_p(torch.cuda.current_stream(idx).cuda_stream)), what)
+
     def workspace(self, N: int, engine: Optional[int] = None) -> torch.Tensor:
         e = self.desc.engine if engine is None else engine
-        need = C.c_int64()
-        check(self.lib.pinn_query_workspace(C.byref(self._d(e)), N, C.byref(need)), "pinn_query_workspace")
+        key = (e, N)
+        need = self._ws_need.get(key)
+        if need is None:
+            c_need = C.c_int64()
+            idx = self._index()
+            if torch.cuda.current_device() != idx:      # the answer depends on the device's CU count
+                with torch.cuda.device(idx):
+                    check(self.lib.pinn_query_workspace(C.byref(self._d(e)), N, C.byref(c_need)), "pinn_query_workspace")
+            else:
+                check(self.lib.pinn_query_workspace(C.byref(self._d(e)), N, C.byref(c_need)), "pinn_query_workspace")
+            need = self._ws_need[key] = c_need.value
         ws = self._ws.get(e)
-        if ws is None or ws.numel() < need.value:
-            self._ws[e] = ws = torch.empty(max(need.value, 256), dtype=torch.uint8, device=self.device)
+        if ws is None or ws.numel() < need:
+            self._ws[e] = ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
         return ws
-
-    @staticmethod
-    def _stream() -> C.c_void_p:
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     # ---- calls ------------------------------------------------------------------------
     def forward(self, params: torch.Tensor, X: torch.Tensor, engine=None) -> torch.Tensor:
         N = X.shape[0]
-        _chk(params, "params", (self.n_params,)); _chk(X, "X", (N, self.desc.d_in))
+        self._chk(params, "params", (self.n_params,)); self._chk(X, "X", (N, self.desc.d_in))
         Y = torch.empty(N, self.desc.d_out, dtype=torch.float32, device=X.device)
         ws = self.workspace(N, engine)
-        check(self.lib.pinn_forward(C.byref(self._d(engine)), _ptr(params), _ptr(X), N, _ptr(Y), _ptr(ws),
-                                    ws.numel(), self._stream()), "pinn_forward")
+        self._run("pinn_forward", self.lib.pinn_forward, C.byref(self._d(engine)), _ptr(params), _ptr(X), N, _ptr(Y), _ptr(ws),
+                  ws.numel())
         return Y
 
     def forward_jet(self, params: torch.Tensor, X: torch.Tensor, engine=None):
         N = X.shape[0]
-        _chk(params, "params", (self.n_params,)); _chk(X, "X", (N, self.desc.d_in))
+        self._chk(params, "params", (self.n_params,)); self._chk(X, "X", (N, self.desc.d_in))
         Y = torch.empty(N, self.desc.d_out, dtype=torch.float32, device=X.device)
         dY = torch.empty(self.desc.k, N, self.desc.d_out, dtype=torch.float32, device=X.device)
         ws = self.workspace(N, engine)
-        check(self.lib.pinn_forward_jet(C.byref(self._d(engine)), _ptr(params), _ptr(X), N, _ptr(Y), _ptr(dY),
-                                        _ptr(ws), ws.numel(), self._stream()), "pinn_forward_jet")
+        self._run("pinn_forward_jet", self.lib.pinn_forward_jet, C.byref(self._d(engine)), _ptr(params), _ptr(X), N, _ptr(Y), _ptr(dY),
+                                        _ptr(ws), ws.numel())
         return Y, dY
 
     def jet_backward(self, params, X, gY: Optional[torch.Tensor], gdY: Optional[torch.Tensor],
                      grad: torch.Tensor) -> torch.Tensor:
         N = X.shape[0]
-        _chk(params, "params", (self.n_params,)); _chk(X, "X", (N, self.desc.d_in))
-        _chk(grad, "grad", (self.n_params,))
-        if gY is not None: _chk(gY, "gY", (N, self.desc.d_out))
-        if gdY is not None: _chk(gdY, "gdY", (self.desc.k, N, self.desc.d_out))
+        self._chk(params, "params", (self.n_params,)); self._chk(X, "X", (N, self.desc.d_in))
+        self._chk(grad, "grad", (self.n_params,))
+        if gY is not None: self._chk(gY, "gY", (N, self.desc.d_out))
+        if gdY is not None: self._chk(gdY, "gdY", (self.desc.k, N, self.desc.d_out))
         ws = self.workspace(N, ENGINE_GENERIC)
-        check(self.lib.pinn_jet_backward(C.byref(self._d(ENGINE_GENERIC)), _ptr(params), _ptr(X), N, _ptr(gY),
-                                         _ptr(gdY), _ptr(grad), _ptr(ws), ws.numel(), self._stream()),
-              "pinn_jet_backward")
+        self._run("pinn_jet_backward", self.lib.pinn_jet_backward, C.byref(self._d(ENGINE_GENERIC)), _ptr(params), _ptr(X), N, _ptr(gY),
+                                         _ptr(gdY), _ptr(grad), _ptr(ws), ws.numel())
         return grad
 
     def residual_loss(self, spec: ResidualSpec, params, X, engine=None) -> torch.Tensor:
         N = X.shape[0]
-        _chk(params, "params", (self.n_params,)); _chk(X, "X", (N, self.desc.d_in))
+        self._chk(params, "params", (self.n_params,)); self._chk(X, "X", (N, self.desc.d_in))
         sums = torch.empty(spec.n_terms, dtype=torch.float32, device=X.device)
         ws = self.workspace(N, engine)
-        check(self.lib.pinn_residual_loss(C.byref(self._d(engine)), C.byref(spec.c_struct()), _ptr(params),
-                                          _ptr(X), N, _ptr(sums), _ptr(ws), ws.numel(), self._stream()),
-              "pinn_residual_loss")
+        self._run("pinn_residual_loss", self.lib.pinn_residual_loss, C.byref(self._d(engine)), C.byref(spec.c_struct()), _ptr(params),
+                                          _ptr(X), N, _ptr(sums), _ptr(ws), ws.numel())
         return sums
 
     def residual_loss_grad(self, spec: ResidualSpec, term_scale: torch.Tensor, params, X, grad: torch.Tensor,
                            engine=None, sums: Optional[torch.Tensor] = None) -> torch.Tensor:
         """grad += sum_t term_scale[t] * d(term_sums[t])/d(params); returns term_sums (device)."""
         N = X.shape[0]
-        _chk(params, "params", (self.n_params,)); _chk(X, "X", (N, self.desc.d_in))
-        _chk(grad, "grad", (self.n_params,)); _chk(term_scale, "term_scale", (spec.n_terms,))
+        self._chk(params, "params", (self.n_params,)); self._chk(X, "X", (N, self.desc.d_in))
+        self._chk(grad, "grad", (self.n_params,)); self._chk(term_scale, "term_scale", (spec.n_terms,))
         if sums is None:
             sums = torch.empty(spec.n_terms, dtype=torch.float32, device=X.device)
         ws = self.workspace(N, engine)
-        check(self.lib.pinn_residual_loss_grad(C.byref(self._d(engine)), C.byref(spec.c_struct()),
+        self._run("pinn_residual_loss_grad", self.lib.pinn_residual_loss_grad, C.byref(self._d(engine)), C.byref(spec.c_struct()),
                                                _ptr(term_scale), _ptr(params), _ptr(X), N, _ptr(sums),
-                                               _ptr(grad), _ptr(ws), ws.numel(), self._stream()),
-              "pinn_residual_loss_grad")
+                                               _ptr(grad), _ptr(ws), ws.numel())
         return sums
 
     def mse_loss_grad(self, params, X, T: torch.Tensor, out_col: Sequence[int],
                       col_scale: Optional[torch.Tensor], grad: Optional[torch.Tensor], engine=None,
                       sums: Optional[torch.Tensor] = None) -> torch.Tensor:
         N, nc = X.shape[0], len(out_col)
-        _chk(params, "params", (self.n_params,)); _chk(X, "X", (N, self.desc.d_in)); _chk(T, "T", (N, nc))
+        self._chk(params, "params", (self.n_params,)); self._chk(X, "X", (N, self.desc.d_in)); self._chk(T, "T", (N, nc))
         if grad is not None:
-            _chk(grad, "grad", (self.n_params,)); _chk(col_scale, "col_scale", (nc,))
+            self._chk(grad, "grad", (self.n_params,)); self._chk(col_scale, "col_scale", (nc,))
         if sums is None:
             sums = torch.empty(nc, dtype=torch.float32, device=X.device)
         oc = (C.c_int32 * nc)(*out_col)
         ws = self.workspace(N, engine)
-        check(self.lib.pinn_mse_loss_grad(C.byref(self._d(engine)), _ptr(params), _ptr(X), _ptr(T), N, nc, oc,
-                                          _ptr(col_scale), _ptr(sums), _ptr(grad), _ptr(ws), ws.numel(),
-                                          self._stream()), "pinn_mse_loss_grad")
+        self._run("pinn_mse_loss_grad", self.lib.pinn_mse_loss_grad, C.byref(self._d(engine)), _ptr(params), _ptr(X), _ptr(T), N, nc, oc,
+                                          _ptr(col_scale), _ptr(sums), _ptr(grad), _ptr(ws), ws.numel())
         return sums
 
     def residual_mse_loss_grad(self, spec: ResidualSpec, term_scale, T: torch.Tensor, out_col: Sequence[int],
                                col_scale, params, X, grad, engine=None, term_sums=None, col_sums=None):
         """One pass over one point set: PDE residual + fidelity columns (train_newmethod.py:122-159)."""
         N, nc = X.shape[0], len(out_col)
-        _chk(params, "params", (self.n_params,)); _chk(X, "X", (N, self.desc.d_in)); _chk(T, "T", (N, nc))
-        _chk(grad, "grad", (self.n_params,)); _chk(term_scale, "term_scale", (spec.n_terms,))
-        _chk(col_scale, "col_scale", (nc,))
+        self._chk(params, "params", (self.n_params,)); self._chk(X, "X", (N, self.desc.d_in)); self._chk(T, "T", (N, nc))
+        self._chk(grad, "grad", (self.n_params,)); self._chk(term_scale, "term_scale", (spec.n_terms,))
+        self._chk(col_scale, "col_scale", (nc,))
         if term_sums is None:
             term_sums = torch.empty(spec.n_terms, dtype=torch.float32, device=X.device)
         if col_sums is None:
             col_sums = torch.empty(nc, dtype=torch.float32, device=X.device)
         oc = (C.c_int32 * nc)(*out_col)
         ws = self.workspace(N, engine)
-        check(self.lib.pinn_residual_mse_loss_grad(C.byref(self._d(engine)), C.byref(spec.c_struct()), _ptr(term_scale),
+        self._run("pinn_residual_mse_loss_grad", self.lib.pinn_residual_mse_loss_grad, C.byref(self._d(engine)), C.byref(spec.c_struct()), _ptr(term_scale),
                                                    _ptr(T), nc, oc, _ptr(col_scale), _ptr(params), _ptr(X), N,
-                                                   _ptr(term_sums), _ptr(col_sums), _ptr(grad), _ptr(ws), ws.numel(),
-                                                   self._stream()), "pinn_residual_mse_loss_grad")
+                                                   _ptr(term_sums), _ptr(col_sums), _ptr(grad), _ptr(ws), ws.numel())
         return term_sums, col_sums
 
     def residual_mse_split_loss_grad(self, spec: ResidualSpec, term_scale, T: torch.Tensor, out_col: Sequence[int],
@@ -276,23 +300,22 @@ class Engine:
         """train.py:131-157 in one launch: X = [n_res collocation points ; fidelity points], T = the
         fidelity targets (N - n_res, n_cols)."""
         N, nc = X.shape[0], len(out_col)
-        _chk(params, "params", (self.n_params,)); _chk(X, "X", (N, self.desc.d_in)); _chk(T, "T", (N - n_res, nc))
-        _chk(grad, "grad", (self.n_params,)); _chk(term_scale, "term_scale", (spec.n_terms,))
-        _chk(col_scale, "col_scale", (nc,))
+        self._chk(params, "params", (self.n_params,)); self._chk(X, "X", (N, self.desc.d_in)); self._chk(T, "T", (N - n_res, nc))
+        self._chk(grad, "grad", (self.n_params,)); self._chk(term_scale, "term_scale", (spec.n_terms,))
+        self._chk(col_scale, "col_scale", (nc,))
         if term_sums is None:
             term_sums = torch.empty(spec.n_terms, dtype=torch.float32, device=X.device)
         if col_sums is None:
             col_sums = torch.empty(nc, dtype=torch.float32, device=X.device)
         oc = (C.c_int32 * nc)(*out_col)
         ws = self.workspace(N, engine)
-        check(self.lib.pinn_residual_mse_split_loss_grad(
+        self._run("pinn_residual_mse_split_loss_grad", self.lib.pinn_residual_mse_split_loss_grad, 
             C.byref(self._d(engine)), C.byref(spec.c_struct()), _ptr(term_scale), _ptr(T), nc, oc, _ptr(col_scale),
-            _ptr(params), _ptr(X), N, int(n_res), _ptr(term_sums), _ptr(col_sums), _ptr(grad), _ptr(ws), ws.numel(),
-            self._stream()), "pinn_residual_mse_split_loss_grad")
+            _ptr(params), _ptr(X), N, int(n_res), _ptr(term_sums), _ptr(col_sums), _ptr(grad), _ptr(ws), ws.numel())
         return term_sums, col_sums
 
     def adam_step(self, params, grad, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8):
         for t, nme in ((params, "params"), (grad, "grad"), (m, "exp_avg"), (v, "exp_avg_sq")):
-            _chk(t, nme, (self.n_params,))
-        check(self.lib.pinn_adam_step(_ptr(params), _ptr(grad), _ptr(m), _ptr(v), self.n_params, step, lr, beta1,
-                                      beta2, eps, self._stream()), "pinn_adam_step")
+            self._chk(t, nme, (self.n_params,))
+        self._run("pinn_adam_step", self.lib.pinn_adam_step, _ptr(params), _ptr(grad), _ptr(m), _ptr(v), self.n_params, step, lr, beta1,
+                                      beta2, eps)

@@ -197,6 +197,11 @@ class FlatLBFGS(_TorchLBFGS):
                 def obj_func(x, step, direction):
                     return self._directional_evaluate(closure, x, step, direction)
 
+                # The line-search budget is whatever the INSTALLED torch.optim.LBFGS.step gives it: torch 2.10
+                # (this image) passes max_ls = max_eval - current_evals; older releases used _strong_wolfe's
+                # default of 25.  tests/test_lbfgs_cpu.py::test_line_search_budget_is_torchs compares
+                # evaluation counts with torch.optim.LBFGS itself, so a torch upgrade that changes the rule
+                # shows up there.
                 loss, g, t, ls_evals = _strong_wolfe(obj_func, x_init, t, d, loss, g, gd, max_ls=max_eval - evals)
                 self._add_grad(t, d)
             else:

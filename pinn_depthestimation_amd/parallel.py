@@ -60,3 +60,19 @@ class Reducer:
             return t
         lo, hi = shard_bounds(t.shape[0], self.rank, self.world)
         return t[lo:hi]
+
+    def gather_rows(self, local: torch.Tensor, n_total: int) -> Optional[torch.Tensor]:
+        """Inverse of shard(): the (n_total, ...) tensor whose contiguous row slices the ranks hold, on
+        rank 0 (None elsewhere).  Shards differ by at most one row, so every rank pads to the largest
+        and ONE all_gather moves the data (collective: every rank must call it)."""
+        if not self.active:
+            return local
+        rows = [shard_bounds(n_total, r, self.world) for r in range(self.world)]
+        most = max(hi - lo for lo, hi in rows)
+        pad = torch.zeros((most,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[:local.shape[0]] = local
+        parts = [torch.empty_like(pad) for _ in range(self.world)]
+        self.dist.all_gather(parts, pad, group=self.group)
+        if self.rank != 0:
+            return None
+        return torch.cat([p[:hi - lo] for p, (lo, hi) in zip(parts, rows)], 0)

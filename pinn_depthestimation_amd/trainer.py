@@ -39,12 +39,13 @@ class HipEvaluator:
     """Local-shard loss sums and gradient through libpinn_hip.so."""
 
     def __init__(self, cfg_layers, init_type, grad_cols, spec: ResidualSpec, fid_cols: Sequence[int], device,
-                 engine: int = 0):
+                 engine: int = 0, precision: int = 0):
         act = ACTIVATION_OF_INIT[init_type]
-        self.eng = Engine(NetDesc.from_layers(cfg_layers, grad_cols, act, engine), device)
+        self.eng = Engine(NetDesc.from_layers(cfg_layers, grad_cols, act, engine, precision), device)
         self.spec, self.fid_cols = spec, list(fid_cols)
         self.merge_sets = True      # one launch for both loss terms when the fidelity set is small
-        self._cat, self._cat_key = None, None
+        self._cat = None            # [collocation points ; fidelity points], allocated once
+        self._cat_src = (None, None)   # the very tensor OBJECTS whose rows _cat currently holds
 
     MERGE_MAX_FID = 2048   # fidelity points ride through the jet kernel (4x their own work): only when few
 
@@ -52,9 +53,19 @@ class HipEvaluator:
         if (self.merge_sets and Xf is not None and Xr is not None and Xf is not Xr
                 and 0 < Xf.shape[0] <= self.MERGE_MAX_FID and Xr.shape[0] > 0):
             # train.py:131-157 in ONE launch: collocation points first, fidelity points after them
-            key = (Xr.data_ptr(), Xf.data_ptr(), Xr.shape[0], Xf.shape[0])
-            if self._cat_key != key:
-                self._cat, self._cat_key = torch.cat((Xr, Xf), 0).contiguous(), key
+            # The merged matrix is refreshed whenever either source is a different tensor OBJECT than the
+            # one it was filled from (held here, so its storage cannot be recycled under us): a resampled
+            # mini-batch is a new tensor every call and is copied in every call.  data_ptr() is no
+            # identity — the caching allocator hands a freed block to the next same-sized tensor.
+            nr, nf = Xr.shape[0], Xf.shape[0]
+            if self._cat is None or self._cat.shape[0] != nr + nf:
+                self._cat = torch.empty(nr + nf, Xr.shape[1], dtype=torch.float32, device=Xr.device)
+                self._cat_src = (None, None)
+            if self._cat_src[0] is not Xr:
+                self._cat[:nr].copy_(Xr)
+            if self._cat_src[1] is not Xf:
+                self._cat[nr:].copy_(Xf)
+            self._cat_src = (Xr, Xf)
             self.eng.residual_mse_split_loss_grad(self.spec, res_scale, Tf, self.fid_cols, fid_scale, theta, self._cat,
                                                   Xr.shape[0], grad, term_sums=res_sums, col_sums=fid_sums)
             return
@@ -87,7 +98,7 @@ class PINN:
                  reducer: Optional[Reducer] = None, evaluator: Optional[Callable] = None,
                  dnn: Optional[DNN] = None, engine: int = 0, mat_dump_iter: Optional[int] = None,
                  mat_dump_path: str = "data_at50k.mat", residual_batch: Optional[int] = None, seed: int = 1234,
-                 log_flush_every: int = 100, lbfgs_impl: str = "flat"):
+                 log_flush_every: int = 100, lbfgs_impl: str = "flat", precision: int = 0):
         cfg = config if isinstance(config, PinnConfig) else load_config(config)
         self.config, self.device = cfg, torch.device(device)
         self.reducer = reducer or Reducer()
@@ -135,7 +146,7 @@ class PINN:
         self.grad = self.buf[:P]
         self._fid_sums, self._res_sums = self.buf[P:P + nf], self.buf[P + nf:]
         self.evaluator = evaluator or HipEvaluator(cfg.layers, cfg.init_type, cfg.grad_cols, self.spec,
-                                                   self.fid_cols, dev, engine)
+                                                   self.fid_cols, dev, engine, precision)
 
         # optional resampled collocation mini-batch (the reference is full-batch only):
         # each closure draws `residual_batch` of this rank's points with a device-side generator
@@ -256,14 +267,18 @@ class PINN:
         self._log_fh.write(f"{it}, {fid:.5e}, {res:.5e}, {tot:.5e}\n")                        # train.py:170
 
     def dump_predictions(self, path: str):
-        """savemat of pred_<key> (N,1) float32 for every network output on the (local) residual
-        points — the file format of the reference's data_at50k.mat (train_newmethod.py:141-153)."""
+        """savemat of pred_<key> (N,1) float32 for every network output on ALL residual points — the
+        file format of the reference's data_at50k.mat (train_newmethod.py:141-153).  Under data
+        parallelism every rank predicts its shard, the shards are gathered in rank order (= the
+        original row order, parallel.shard_bounds) and rank 0 alone writes the file."""
+        Y = self.reducer.gather_rows(self.predict(self.Xr).detach(), self.n_res)
+        if self.reducer.rank != 0:
+            return
         from scipy.io import savemat
-        Y = self.predict(self.Xr).detach().cpu().numpy().astype(np.float32)
+        Y = Y.cpu().numpy().astype(np.float32)
         names = self.config.residual_outputs
         savemat(path, {f"pred_{k}": Y[:, i:i + 1] for i, k in enumerate(names)})
-        if self.reducer.rank == 0:
-            print(f"Data saved to {path} after {self.iter} iterations.")
+        print(f"Data saved to {path} after {self.iter} iterations.")
 
     def save_checkpoint(self, name: str):
         self.flush_log()

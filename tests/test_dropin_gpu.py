@@ -186,16 +186,53 @@ def test_g8_lbfgs_from_adam_end_state():
     got = np.array([h[3] for h in tr.history])
     ref = z["losses"]
     assert abs(got[0] - ref[0]) / ref[0] < 5e-6
-    # line-search decisions amplify rounding: compare the descent, not every evaluation
-    n = min(len(got), len(ref), 10)
-    assert np.max(np.abs(got[:n] - ref[:n]) / ref[:n]) < 1e-3
-    assert got[-1] < ref[0] * 0.1 and abs(np.log(got[-1] / ref[-1])) < 0.5
+    # Line-search decisions amplify rounding, and the reference does it to itself: G8s is the same
+    # torch.optim.LBFGS run at 1 thread instead of 8 — its closure losses differ from G8's by 2.6e-5 over the
+    # first 10 evaluations, 9.7e-5 over the first 20 and 1.2e-2 by the end.  Asserted: SURVEY §8c's 1e-4 on the
+    # leading 10 evaluations (= 4x the reference's own spread there), 4x its spread on the first 20, and the
+    # end of the descent within 4x the reference's end-of-run spread.
+    spread = load("g8s_lbfgs_thread_spread.npz")["spread"]
+    n = min(len(got), len(ref))
+    rel = np.abs(got[:n] - ref[:n]) / ref[:n]
+    print("G8 torch-LBFGS closure losses vs reference: first 10 %.2e, first 20 %.2e, all %.2e (reference's own "
+          "thread spread: %.2e / %.2e / %.2e)" % (rel[:10].max(), rel[:20].max(), rel.max(), spread[:10].max(),
+                                                    spread[:20].max(), spread.max()))
+    assert n >= 20
+    assert rel[:10].max() < max(1e-4, 4 * spread[:10].max())
+    assert rel[:20].max() < 4 * spread[:20].max()
+    assert abs(np.log(got[-1] / ref[-1])) < max(0.05, 4 * spread.max())
+
+
+def test_g8b_scipy_lbfgsb_trajectory():
+    """a9 (second half): the SciPy L-BFGS-B stage over the flat closure, against the same
+    scipy.optimize.minimize run over a closure built from the REFERENCE's dnn.DNN / physics.Navier_Stokes
+    (make_goldens_r2.py g8b; start = G7 end state, N = 2000, maxcor 50, maxls 50, 50 iterations).
+    Every closure evaluation is compared: 1e-4 on the first 10 accepted iterates' evaluations, final loss
+    within 5 %."""
+    from pinn_depthestimation_amd.lbfgsb import LBFGSBOptimizer
+    from pinn_depthestimation_amd.trainer import pinn
+    import dnn
+    z7, z = load("g7_adam_ns_8x64.npz"), load("g8b_scipy_lbfgsb_ns_8x64.npz")
+    model = dnn.DNN([3] + [64] * 8 + [4], 0.0, "xavier")
+    model.load_state_dict(state_dict(z7, "sd_end/"))
+    tr = pinn(None, None, z7["X"][:2000], ns_config(0), dnn=model, log_every=1, checkpoint_every=0)
+    opt = LBFGSBOptimizer(tr, {"maxiter": 50, "maxfun": 50000})
+    res = opt.minimize()
+    got, ref = np.array(opt.losses[:-1]), z["evals"]            # (the last entry re-evaluates the end point)
+    n = min(len(got), len(ref))
+    rel = np.abs(got[:n] - ref[:n]) / ref[:n]
+    print("G8b SciPy L-BFGS-B: %d / %d evaluations, nit %d / %d; rel diff first 12 evals %.2e, all %.2e; final %.4e vs %.4e"
+          % (len(got), len(ref), res.nit, int(z["nit"]), rel[:12].max(), rel.max(), res.fun, float(z["fun"])))
+    assert abs(got[0] - ref[0]) / ref[0] < 5e-6
+    assert n >= 12 and rel[:12].max() < 1e-4                     # >= 10 accepted iterates (53 evals for 50 iterations)
+    assert abs(res.fun - float(z["fun"])) / float(z["fun"]) < 0.05
+    assert res.nit == int(z["nit"])
 
 
 def test_g9_newmethod_on_data_at50k_columns():
     from pinn_depthestimation_amd.trainer import pinn
     import dnn
-    z = load("g9_newmethod_at50k.npz")
+    z, zx = load("g9_newmethod_at50k.npz"), load("g9x_newmethod_fp64.npz")
     T = np.concatenate([z["U"], z["V"]], 1)
     for tag, hidden, width, tol in (("8x64", 8, 64, 1e-5), ("100x20", 100, 20, 1e-4)):
         cfg = {"layers": {"input_features": 2, "hidden_layers": hidden, "hidden_width": width, "output_features": 3,
@@ -210,9 +247,16 @@ def test_g9_newmethod_on_data_at50k_columns():
         model.load_state_dict(sd)
         tr = pinn(z["X"], T, z["X"], cfg, dnn=model, log_every=1, checkpoint_every=0)
         tr.loss_func()
-        assert abs(tr.last[0].item() - float(z[f"{tag}/fid0"])) / float(z[f"{tag}/fid0"]) < 5e-6
-        assert abs(tr.last[1].item() - float(z[f"{tag}/res0"])) / float(z[f"{tag}/res0"]) < 10 * tol
-        assert rel_l2(tr.grad.cpu(), z[f"{tag}/grad0"]) < 10 * tol
+        # first iteration against the reference's fp64 evaluation of the same state (g9x), tolerance = the
+        # engine's usual fp32 bars or 4x the reference's own fp32-vs-fp64 disagreement, whichever is larger
+        e_fid = abs(tr.last[0].item() - float(zx[f"{tag}/fid64"])) / float(zx[f"{tag}/fid64"])
+        e_res = abs(tr.last[1].item() - float(zx[f"{tag}/res64"])) / float(zx[f"{tag}/res64"])
+        e_grad = rel_l2(tr.grad.cpu(), zx[f"{tag}/grad64"])
+        print(f"G9 {tag}: vs reference fp64: fid {e_fid:.2e} res {e_res:.2e} grad {e_grad:.2e} (reference fp32: "
+              f"{float(zx[f'{tag}/ref_fid_err']):.1e} {float(zx[f'{tag}/ref_res_err']):.1e} {float(zx[f'{tag}/ref_grad_err']):.1e})")
+        assert e_fid < max(5e-6, 4 * float(zx[f"{tag}/ref_fid_err"]))
+        assert e_res < max(5e-6, 4 * float(zx[f"{tag}/ref_res_err"]))
+        assert e_grad < max(2e-5, 4 * float(zx[f"{tag}/ref_grad_err"]))
         tr.iter, tr.history = 0, []
         tr.train()
         got = np.array([h[3] for h in tr.history])

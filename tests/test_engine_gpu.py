@@ -9,7 +9,8 @@ import torch
 
 from oracle import pinn_oracle as O
 from pinn_depthestimation_amd import Engine, NetDesc, ResidualSpec
-from pinn_depthestimation_amd._lib import ACT_LEAKY_RELU, ACT_TANH, ENGINE_FUSED, ENGINE_GENERIC
+from pinn_depthestimation_amd._lib import (ACT_LEAKY_RELU, ACT_TANH, ENGINE_FUSED, ENGINE_FUSED_COOP, ENGINE_FUSED_TILE,
+                                           ENGINE_GENERIC)
 
 pytestmark = pytest.mark.gpu
 
@@ -59,14 +60,21 @@ def rel_l2(a, b):
 ENGINES = [ENGINE_GENERIC, ENGINE_FUSED]
 
 
-@pytest.fixture(autouse=True, params=["tile", "coop", "pair"])
+@pytest.fixture(autouse=True, params=["tile", "coop"])
 def fused_kernel_choice(request, monkeypatch):
-    """The fused engine has three kernels at padded width 64: one wave per 16-point tile (k_fused), four
-    waves per tile (k_fused_coop, picked automatically for small N) and the opt-in two-waves-per-SIMD
-    8-point layout (k_fused_pair, even jets).  Every test in this module runs with each forced in turn
-    (the library reads PINN_FUSED_COOP / PINN_FUSED_PAIR per call; other shapes ignore them)."""
-    monkeypatch.setenv("PINN_FUSED_COOP", "1" if request.param == "coop" else "0")
-    monkeypatch.setenv("PINN_FUSED_PAIR", "1" if request.param == "pair" else "0")
+    """The fused engine has two kernels at padded width 64: one wave per 16-point tile (k_fused) and four
+    waves per tile (k_fused_coop, picked automatically for small N).  Every test in this module runs with
+    each forced in turn through the descriptor (pinn_desc.engine = PINN_ENGINE_FUSED_TILE / _COOP — the
+    library reads no environment variables); narrower networks have the tile kernel only."""
+    orig = NetDesc.c_struct
+
+    def c_struct(self):
+        d = orig(self)
+        if d.engine == ENGINE_FUSED:
+            coop = request.param == "coop" and 32 < self.width <= 64
+            d.engine = ENGINE_FUSED_COOP if coop else ENGINE_FUSED_TILE
+        return d
+    monkeypatch.setattr(NetDesc, "c_struct", c_struct)
     return request.param
 
 

@@ -67,3 +67,35 @@ def test_fp32_descent_and_second_step_continues_history():
     opt.step(closure)                                         # state (history, d, t) carried over, as in torch
     assert losses[-1] < first < losses[0]
     assert opt.state[theta]["n_iter"] == 20
+
+
+def _stiff_run(opt_cls, max_iter, max_eval):
+    """sum sqrt(1 + (a_i x_i)^2): asymptotically linear, curvatures 1 : 900 — quasi-Newton steps overshoot
+    and single line searches take several evaluations (more than a small max_eval leaves)."""
+    a = torch.tensor([1.0, 30.0, 0.2, 5.0], dtype=torch.float64)
+    x = torch.nn.Parameter(torch.tensor([3.0, -2.0, 40.0, 1.0], dtype=torch.float64))
+    opt = opt_cls([x], lr=1.0, max_iter=max_iter, max_eval=max_eval, history_size=10, tolerance_grad=1e-14,
+                  tolerance_change=1e-16, line_search_fn="strong_wolfe")
+    trace = []
+
+    def closure():
+        opt.zero_grad()
+        loss = torch.sqrt(1 + (a * x) ** 2).sum()
+        loss.backward()
+        trace.append(float(loss.detach()))
+        return loss
+    opt.step(closure)
+    return x.detach().clone(), trace, opt.state[x]["func_evals"]
+
+
+@pytest.mark.parametrize("max_iter,max_eval", [(2, 3), (5, 6), (10, 12), (40, None)])
+def test_line_search_budget_is_torchs(max_iter, max_eval):
+    """The per-search evaluation budget must be the installed torch.optim.LBFGS's (torch 2.10: max_ls =
+    max_eval - evaluations so far; releases before it: 25).  In the first two cases a single line search
+    wants more evaluations than max_eval leaves, so any other rule changes the evaluation count."""
+    a = _stiff_run(torch.optim.LBFGS, max_iter, max_eval)
+    b = _stiff_run(FlatLBFGS, max_iter, max_eval)
+    assert a[2] == b[2], (a[2], b[2])
+    assert len(a[1]) == len(b[1])
+    assert torch.allclose(torch.tensor(a[1]), torch.tensor(b[1]), rtol=1e-9, atol=1e-14)
+    assert (a[0] - b[0]).abs().max() < 1e-9
