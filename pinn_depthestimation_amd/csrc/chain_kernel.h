@@ -1,0 +1,493 @@
+// chain_kernel.h — bf16-MFMA engine for hidden widths 64 < W <= 256 (BASELINE configs[3]: 12 x 256,
+// "bf16 MFMA with fp32 residual accumulate"): the W x W hidden layers of the network are walked by THREE
+// kernels per point chunk instead of three launches per layer (wide_kernel.h, which stays the fp32 path):
+//
+//   k_chain_fwd    per 16-point tile and wave: a_1 -> a_2 -> ... -> a_L through all hidden layers; the jet
+//                  (value + k tangents) lives in registers as the NEXT layer's MFMA B operand, the weights
+//                  stream through an LDS ring shared by the workgroup's four waves (one LDS-DMA copy per
+//                  workgroup instead of one L2 read per wave); every a_l is written once for the reverse sweep.
+//   k_chain_bwd    the reverse chain: abar_L -> zbar_{L-1} -> abar_{L-1} -> ... -> abar_1 with the adjoint kept in
+//                  the fp32 accumulators between layers (never rounded to bf16, never through HBM); reads each
+//                  a_l once, writes each zbar_l once.
+//   k_chain_wgrad  dW_l = sum_points zbar_l (x) a_l for ALL hidden layers in one launch: a workgroup owns one
+//                  layer's whole 256 x 256 gradient in registers for its slice of the points (dW-stationary),
+//                  streams zbar_l / a_l tiles through an LDS ring by LDS-DMA and takes the MFMA operands
+//                  out of it with ds_read_b64_tr_b16 (the hardware transpose: contraction over points).
+//
+// HBM traffic per point and hidden layer: 2 KB (a written) + 2 + 2 (a, zbar in the reverse chain) + 4 (weight
+// gradient) = 10 KB, against 16 KB for one launch per layer; weights come from L2 once per workgroup and layer.
+//
+// MFMA: v_mfma_f32_16x16x32_bf16 (the full-rate gfx950 form: 8 bf16 per lane and operand).  "acc layout =
+// operand layout" carries over from fused_kernel.h with K = 32: lane (p = lane&15 point, q = lane>>4) holds, for
+// k-step s, the 8 values j = 4h + r  <->  unit 32s + 16h + 4q + r, i.e. register r of accumulator tiles
+// MT = 2s + h — two accumulator tiles, converted pairwise to bf16, ARE the B operand of k-step s.  The weights are
+// packed to match (k index permuted inside each k-step, pinn_chain.hip k_chain_pack).
+//
+// Precision: bf16 operands, fp32 accumulate.  Jets (a_l, zbar_l) carry 8 significant bits.  The WEIGHTS are
+// split hi + lo (two bf16, two MFMAs): rounding the weights themselves to bf16 moves this loss by 1.1e-2 and its
+// gradient by 1.2e-1 (measured on the reference's 12 x 256 golden, tests/test_config3_gpu.py — a PINN's loss
+// surface is stiff), the jets' rounding by 1.8e-3 / 3.8e-3; the kernels are bound by HBM, not by the matrix pipe,
+// so the second MFMA is free.
+//
+// Jet storage ("chain layout", bf16): block (tile t, quantity c, k-step s) = 1 KB = [point p (16)][32 units], the
+// 32 units ordered q, h, r — lane (p, q)'s 16 bytes are its B operand of k-step s, at byte (4p + q) * 16.  One
+// wave-level 16-byte load or store moves exactly one contiguous block; a (point, 4 consecutive units) group is
+// 8 contiguous bytes, which is what ds_read_b64_tr_b16 gathers.
+#pragma once
+#include "wide_kernel.h"
+
+namespace pinn {
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef short sh4 __attribute__((ext_vector_type(4)));
+
+constexpr int CHAIN_WAVES = 4;
+constexpr int CHAIN_THREADS = CHAIN_WAVES * 64;
+constexpr int CHAIN_RING = 6;              // weight slabs in the LDS ring (fwd / bwd chain)
+constexpr int WG_UNITS = 4;                // LDS ring slots of the weight-gradient kernel (half tiles)
+
+struct ChainParams {
+  int L;                      // hidden layers of the network (L - 1 hidden W x W matrices: layers 1 .. L-1)
+  int64_t n_tiles;            // tiles in this chunk
+  int64_t jet_stride;         // elements (bf16) between consecutive layers' jets
+  const unsigned short* Wf;   // packed weight fragments, layers 1 .. L-1 (fwd) — see k_chain_pack
+  const unsigned short* WTf;  // packed transposed weight fragments (bwd)
+  const float* bias;          // padded biases, fp32: layer l at bias + l * WP
+  unsigned short* A;          // a_1 at A, a_2 at A + jet_stride, ... a_L
+  unsigned short* Z;          // zbar_1 at Z, ... zbar_{L-1}
+  unsigned short* GL;         // abar_L (input of the reverse chain)
+  unsigned short* G1;         // abar_1 (its output)
+  float* dW;                  // flat torch-layout gradient (wgrad)
+  int spill;                  // fwd: 0 = forward only (no a_l stores except a_L)
+  int W;                      // real hidden width
+  int n_slices;               // wgrad: point slices per layer
+  int64_t w_off1, w_per;      // flat offsets: W_1 at w_off1, W_{l+1} - W_l = w_per; b_l at w_off(l) + W*W
+};
+
+__device__ __forceinline__ f4 mfma32(bf8 a, bf8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// 1 KB LDS-DMA copy: lane i moves 16 bytes from src + 16 i to lds_dst + 16 i (lds_dst wave-uniform)
+__device__ __forceinline__ void dma_1k(const void* src, void* lds_dst, int lane) {
+  __builtin_amdgcn_global_load_lds(
+      (const void __attribute__((address_space(1)))*)((const char*)src + lane * 16),
+      (void __attribute__((address_space(3)))*)lds_dst, 16, 0, 0);
+}
+
+__device__ __forceinline__ float bf2f(__bf16 v) { return (float)v; }
+
+// Jet block access through BUFFER instructions: a scalar resource (base = this wave's tile inside one jet, range =
+// the tile's K1 * NS KB: out-of-range accesses are dropped by the hardware), ONE 32-bit per-lane byte offset and a
+// scalar block offset.  With plain pointers the compiler builds a 64-bit VGPR address per block, hoists them out
+// of the loops and spills them by the hundred (506 spilled registers in k_chain_bwd at K1 = 4).
+typedef unsigned u4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t jet_rsrc(const void* tile_base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(tile_base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ bf8 ld_blk(__amdgpu_buffer_rsrc_t r, unsigned lane_off, int blk_off) {
+  return __builtin_bit_cast(bf8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_off, blk_off, 0));
+}
+__device__ __forceinline__ void st_blk(__amdgpu_buffer_rsrc_t r, unsigned lane_off, int blk_off, bf8 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, (int)lane_off, blk_off, 0);
+}
+
+// a wave-uniform 64-bit value the compiler cannot prove uniform (derived from threadIdx): moved to SGPRs so
+// that jet accesses become  scalar base + one 32-bit lane offset + immediate  instead of 64-bit VGPR addresses
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(v & 0xffffffffll));
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+  return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+
+// tanh for values that are rounded to 8 significant bits right afterwards: 1 - 2 / (exp(2x) + 1), absolute
+// error ~1e-7 (v_exp_f32 + v_rcp_f32); the polynomial branch of residuals.h::tanh_f32 buys nothing here.
+__device__ __forceinline__ float tanh_bf(float x) {
+  const float e = __expf(2.f * x);
+  return fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
+}
+
+
+// The weight ring of the two chain kernels.  Slabs are consumed in a fixed order (tile batch, layer, output tile);
+// `next` walks that order one slab ahead of the R - 1 in flight.  Everything is wave-uniform.
+template <int NTW, int SLAB, int R, bool DESCENDING>
+struct SlabRing {
+  const char* base; char* lds; int nh, wave, lane;
+  int64_t issued, total;      // slabs issued so far / slabs this workgroup consumes
+  int li, MT, slot;           // of the next slab to issue
+  int cslot;                  // ring slot of the slab being consumed
+  __device__ __forceinline__ void init(const void* w, char* smem, int nh_, int64_t total_, int wave_, int lane_) {
+    base = (const char*)w; lds = smem; nh = nh_; total = total_; wave = wave_; lane = lane_;
+    issued = 0; li = DESCENDING ? nh - 1 : 0; MT = 0; slot = 0; cslot = 0;
+  }
+  __device__ __forceinline__ void issue() {
+    if (issued >= total) return;
+    constexpr int QDMA = SLAB / 4 / 1024;
+    const char* src = base + ((int64_t)(li * NTW + MT)) * SLAB + wave * (SLAB / 4);
+    char* dst = lds + slot * SLAB + wave * (SLAB / 4);
+#pragma unroll
+    for (int i = 0; i < QDMA; ++i) dma_1k(src + i * 1024, dst + i * 1024, lane);
+    ++issued;
+    slot = slot + 1 == R ? 0 : slot + 1;
+    if (++MT == NTW) { MT = 0; li = DESCENDING ? (li == 0 ? nh - 1 : li - 1) : (li + 1 == nh ? 0 : li + 1); }
+  }
+  // Before consuming slab number `g` (0-based): its copies (this wave's quarter) have landed once at most the
+  // copies of the R - 2 younger slabs — plus `extra` stores this wave issued after them — are outstanding.
+  // Near the end of the sequence fewer younger slabs exist: drain everything.
+  template <int EXTRA>
+  __device__ __forceinline__ void wait_landed(int64_t g, bool extra_issued) {
+    constexpr int QDMA = SLAB / 4 / 1024;
+    constexpr int N = (R - 2) * QDMA;
+    if (g + R - 1 > total) wait_vm<0>();           // (issue() has been skipping: fewer than R - 2 younger slabs)
+    else if (EXTRA > 0 && N + EXTRA <= 63 && extra_issued) wait_vm<(N + EXTRA <= 63 ? N + EXTRA : N)>();
+    else wait_vm<N>();
+  }
+  __device__ __forceinline__ const char* consume_ptr() const { return lds + cslot * SLAB + lane * 16; }
+  __device__ __forceinline__ void consumed() { cslot = cslot + 1 == R ? 0 : cslot + 1; }
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// Forward chain.  Weight slab (layer l, output tile MT) = [hi | lo][k-step s][lane][8 bf16]: NS * 2 KB.
+template <int NTW, int K1>
+__global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_fwd(const ChainParams P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NS = NTW / 2;
+  constexpr int SLAB = NS * 2 * 1024;              // bytes
+  constexpr int R = CHAIN_RING;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4;
+  const unsigned lpos = (4u * (lane & 15) + q) * 16u;  // BYTE offset of this lane inside a jet block
+  const int nh = P.L - 1;                          // hidden matrices
+  const int64_t n_tb = (P.n_tiles + CHAIN_WAVES - 1) / CHAIN_WAVES;
+  const int64_t my_tb = (n_tb - blockIdx.x + gridDim.x - 1) / gridDim.x;   // tile batches of this workgroup
+  SlabRing<NTW, SLAB, R, false> ring;
+  ring.init(P.Wf, smem, nh, my_tb * nh * NTW, wave, lane);
+  for (int g0 = 0; g0 < R - 1; ++g0) ring.issue();
+  int64_t g = 0;
+  bool stored = false;                             // did this wave issue its K1 * NS jet stores in the last activation?
+  for (int64_t tb = blockIdx.x; tb < n_tb; tb += gridDim.x) {
+    int64_t t = tb * CHAIN_WAVES + wave;
+    const bool live = t < P.n_tiles;               // wave-uniform; dead waves keep the ring protocol going
+    if (!live) t = P.n_tiles - 1;
+    const int64_t tbase = uniform64(t) * (K1 * NS * 512);   // element offset of this wave's tile inside a jet
+    constexpr int TILE_BYTES = K1 * NS * 1024;
+    const __amdgpu_buffer_rsrc_t a1r = jet_rsrc(P.A + tbase, TILE_BYTES);
+    bf8 bj[K1][NS];
+#pragma unroll
+    for (int c = 0; c < K1; ++c)
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+        bj[c][s] = ld_blk(a1r, lpos, (c * NS + s) * 1024);
+    for (int l = 1; l <= nh; ++l) {
+      f4 acc[K1][NTW];
+      zero_tiles<NTW, K1>(acc);
+#pragma unroll
+      for (int MT = 0; MT < NTW; ++MT) {
+        // (the first R - 1 steps of a layer: the activation's stores are younger than slab g's copies)
+        if (MT < R - 1) ring.template wait_landed<K1 * NS>(g, stored);
+        else ring.template wait_landed<0>(g, false);
+        __builtin_amdgcn_s_barrier();              // every quarter landed; every wave is done with slab g - 1
+        ring.issue();                              // ... whose ring slot is refilled now
+        const char* sl = ring.consume_ptr();
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const bf8 ahi = *reinterpret_cast<const bf8*>(sl + s * 1024);
+          const bf8 alo = *reinterpret_cast<const bf8*>(sl + (NS + s) * 1024);
+#pragma unroll
+          for (int c = 0; c < K1; ++c) {
+            acc[c][MT] = mfma32(ahi, bj[c][s], acc[c][MT]);
+            acc[c][MT] = mfma32(alo, bj[c][s], acc[c][MT]);
+          }
+        }
+        ring.consumed();
+        ++g;
+      }
+      // activation (dnn.py:36-37): a = tanh(z + b), adot_j = (1 - a^2) zdot_j; packed straight into the next
+      // layer's B operand and written out once for the reverse sweep
+      const float* __restrict__ bl = P.bias + l * (16 * NTW);
+      const __amdgpu_buffer_rsrc_t dst = jet_rsrc(P.A + (int64_t)l * P.jet_stride + tbase, TILE_BYTES);
+      stored = live && (P.spill || l == nh);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        float o[K1][8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f4 b4 = *reinterpret_cast<const f4*>(bl + 16 * (2 * s + h) + 4 * q);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float a = tanh_bf(acc[0][2 * s + h][r] + b4[r]);
+            const float sv = fmaf(-a, a, 1.f);
+            o[0][4 * h + r] = a;
+#pragma unroll
+            for (int c = 1; c < K1; ++c) o[c][4 * h + r] = acc[c][2 * s + h][r] * sv;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < K1; ++c) {
+          bf8 v;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (__bf16)o[c][j];
+          bj[c][s] = v;
+          if (stored) st_blk(dst, lpos, (c * NS + s) * 1024, v);
+        }
+      }
+    }
+  }
+  wait_vm<0>();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Reverse chain.  State between layers: abar_{l+1} in the fp32 accumulators.  Per hidden matrix l (L-1 .. 1):
+//   zbar_l = activation adjoint(abar_{l+1}, a_{l+1})   (fused_kernel.h activate_adjoint: tanh'' term included)
+//   store zbar_l (weight-gradient operand);  abar_l = W_l^T zbar_l  (same chain on the packed W^T)
+template <int NTW, int K1>
+__global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_bwd(const ChainParams P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NS = NTW / 2;
+  constexpr int SLAB = NS * 2 * 1024;
+  constexpr int R = CHAIN_RING;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4;
+  const unsigned lpos = (4u * (lane & 15) + q) * 16u;
+  const int nh = P.L - 1;
+  const int64_t n_tb = (P.n_tiles + CHAIN_WAVES - 1) / CHAIN_WAVES;
+  const int64_t my_tb = (n_tb - blockIdx.x + gridDim.x - 1) / gridDim.x;
+  SlabRing<NTW, SLAB, R, true> ring;               // slab order: layers nh-1 .. 0 (descending), tiles 0 .. NTW-1
+  ring.init(P.WTf, smem, nh, my_tb * nh * NTW, wave, lane);
+  for (int g0 = 0; g0 < R - 1; ++g0) ring.issue();
+  int64_t g = 0;
+  for (int64_t tb = blockIdx.x; tb < n_tb; tb += gridDim.x) {
+    int64_t t = tb * CHAIN_WAVES + wave;
+    const bool live = t < P.n_tiles;
+    if (!live) t = P.n_tiles - 1;
+    const int64_t tbase = uniform64(t) * (K1 * NS * 512);
+    constexpr int TILE_BYTES = K1 * NS * 1024;
+    const __amdgpu_buffer_rsrc_t glp = jet_rsrc(P.GL + tbase, TILE_BYTES);
+    f4 acc[K1][NTW];
+    for (int l = nh; l >= 1; --l) {
+      // ---- activation adjoint on a_{l+1} (stored at A + l * jet_stride) -> zbar_l as the next B operand.
+      // abar_{l+1} sits in the accumulators, except for l = nh: abar_L comes from the output layer's reverse
+      // kernel (bf16, chain layout) and is read piece by piece next to a_L — preloading it into the accumulators
+      // made the compiler keep a VGPR copy of all 64 K1 values beside the AGPR one (330 spilled registers).
+      const __amdgpu_buffer_rsrc_t aop = jet_rsrc(P.A + (int64_t)l * P.jet_stride + tbase, TILE_BYTES);
+      const __amdgpu_buffer_rsrc_t zdst = jet_rsrc(P.Z + (int64_t)(l - 1) * P.jet_stride + tbase, TILE_BYTES);
+      bf8 zj[K1][NS];
+      // a_{l+1} arrives in k-step pieces, requested AHEAD pieces before their use and no earlier (left alone the
+      // compiler hoists every load of the phase to its top)
+      auto phase = [&](auto from_mem) {
+        constexpr bool MEM = decltype(from_mem)::value;
+        constexpr int AHEAD = MEM ? 1 : 2;         // (two streams in the first phase: half the look-ahead each)
+        bf8 av[AHEAD + 1][K1], gv[MEM ? AHEAD + 1 : 1][K1];
+        auto request = [&](int s2, int slot) {
+#pragma unroll
+          for (int c = 0; c < K1; ++c) {
+            av[slot][c] = ld_blk(aop, lpos, (c * NS + s2) * 1024);
+            if constexpr (MEM) gv[slot][c] = ld_blk(glp, lpos, (c * NS + s2) * 1024);
+          }
+        };
+#pragma unroll
+        for (int s0 = 0; s0 < AHEAD && s0 < NS; ++s0) request(s0, s0 % (AHEAD + 1));
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          if (s + AHEAD < NS) request(s + AHEAD, (s + AHEAD) % (AHEAD + 1));
+          const int cs = s % (AHEAD + 1);
+          float o[K1][8];
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int j = 4 * h + r;
+              const float a = bf2f(av[cs][0][j]);
+              const float sv = fmaf(-a, a, 1.f);
+              float cross = 0.f;
+              float ab[K1];
+#pragma unroll
+              for (int c = 0; c < K1; ++c) {
+                if constexpr (MEM) ab[c] = bf2f(gv[cs][c][j]);
+                else ab[c] = acc[c][2 * s + h][r];
+              }
+#pragma unroll
+              for (int c = 1; c < K1; ++c) {
+                cross = fmaf(ab[c], bf2f(av[cs][c][j]), cross);
+                o[c][j] = ab[c] * sv;
+              }
+              o[0][j] = fmaf(-2.f * a, cross, sv * ab[0]);   // tanh'' = -2 a (1 - a^2)
+            }
+#pragma unroll
+          for (int c = 0; c < K1; ++c) {
+            bf8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (__bf16)o[c][j];
+            zj[c][s] = v;
+            if (live) st_blk(zdst, lpos, (c * NS + s) * 1024, v);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      if (l == nh) phase(std::true_type{});
+      else phase(std::false_type{});
+      // ---- abar_l = W_l^T zbar_l
+      zero_tiles<NTW, K1>(acc);
+#pragma unroll
+      for (int MT = 0; MT < NTW; ++MT) {
+        if (MT < R - 1) ring.template wait_landed<K1 * NS>(g, live);   // (zbar stores of the adjoint phase above)
+        else ring.template wait_landed<0>(g, false);
+        __builtin_amdgcn_s_barrier();
+        ring.issue();
+        const char* sl = ring.consume_ptr();
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const bf8 ahi = *reinterpret_cast<const bf8*>(sl + s * 1024);
+          const bf8 alo = *reinterpret_cast<const bf8*>(sl + (NS + s) * 1024);
+#pragma unroll
+          for (int c = 0; c < K1; ++c) {
+            acc[c][MT] = mfma32(ahi, zj[c][s], acc[c][MT]);
+            acc[c][MT] = mfma32(alo, zj[c][s], acc[c][MT]);
+          }
+        }
+        ring.consumed();
+        ++g;
+      }
+    }
+    // abar_1 for the first layer's reverse kernel (bf16: it is consumed together with the bf16 a_1)
+    if (live) {
+      const __amdgpu_buffer_rsrc_t g1r = jet_rsrc(P.G1 + tbase, TILE_BYTES);
+#pragma unroll
+      for (int c = 0; c < K1; ++c)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          bf8 v;
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * h + r] = (__bf16)acc[c][2 * s + h][r];
+          st_blk(g1r, lpos, (c * NS + s) * 1024, v);
+        }
+    }
+  }
+  wait_vm<0>();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Weight gradient of all hidden matrices in one launch.  Workgroup b -> (layer li = b % nh, slice b / nh); wave w
+// owns output-unit tiles [w * MTB, (w + 1) * MTB) x all NTW input tiles of dW_l in registers.  The contraction
+// runs over (quantity c, point p): per tile two k-steps of 32 — k-step u holds quantities 2u, 2u + 1 (lane group
+// qk: quantity 2u + (qk >> 1), points 8 (qk & 1) .. + 7).  Ring unit = (tile, k-step): the zbar and a blocks of two
+// quantities, 2 * 2 * NS KB, copied by LDS-DMA; operands by ds_read_b64_tr_b16 (4 points x 16 units per 16 lanes).
+__device__ __forceinline__ sh4 ds_tr(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((sh4 __attribute__((address_space(3)))*)p);
+}
+__device__ __forceinline__ bf8 tr_operand(const char* p0) {   // two transposed reads 4 points apart -> 8 k values
+  const sh4 a = ds_tr(p0), b = ds_tr(p0 + 4 * 64);
+  typedef short sh8 __attribute__((ext_vector_type(8)));
+  const sh8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf8, v);
+}
+
+template <int NTW, int K1>
+__global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_wgrad(const ChainParams P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NS = NTW / 2;
+  constexpr int MTB = NTW / CHAIN_WAVES;           // output tiles per wave: 4 (W = 256) or 2 (W = 128)
+  constexpr int KU = (K1 + 1) / 2;                 // k-steps per tile
+  constexpr int HALF = 2 * NS * 1024;              // bytes of one operand's two quantities
+  constexpr int UNIT = 2 * HALF;                   // [zbar c0 | zbar c1 | a c0 | a c1] x NS blocks
+  constexpr int UDMA = UNIT / 1024 / CHAIN_WAVES;  // 1 KB copies per wave and unit
+  constexpr int RU = WG_UNITS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i16 = lane & 15, qk = lane >> 4;
+  const int nh = P.L - 1;
+  const int li = blockIdx.x % nh, slice = blockIdx.x / nh;
+  if (slice >= P.n_slices) return;                 // (workgroup-uniform)
+  const int64_t t0 = P.n_tiles * slice / P.n_slices, t1 = P.n_tiles * (slice + 1) / P.n_slices;
+  const int64_t U = (t1 - t0) * KU;                // ring units this workgroup consumes
+  const unsigned short* Zl = P.Z + (int64_t)li * P.jet_stride;        // zbar_{li+1}
+  const unsigned short* Al = P.A + (int64_t)li * P.jet_stride;        // a_{li+1} (the layer's input)
+  auto issue_unit = [&](int64_t u) {
+    if (u >= U) return;
+    const int64_t t = t0 + u / KU;
+    const int ku = (int)(u % KU);
+    char* dst = smem + (int)(u % RU) * UNIT;
+    // copy j of this wave: j' = wave * UDMA + j in [0, 4 NS): operand (j' / (2 NS)), quantity 2 ku + (j' / NS) % 2, block j' % NS
+#pragma unroll
+    for (int j = 0; j < UDMA; ++j) {
+      const int jj = wave * UDMA + j;
+      const int op = jj / (2 * NS), cq = (jj / NS) & 1, s = jj % NS;
+      int c = 2 * ku + cq;
+      if (c >= K1) c = K1 - 1;                     // odd K1: the missing quantity is masked at the MFMA operand
+      const unsigned short* src = (op ? Al : Zl) + ((t * K1 + c) * NS + s) * 512;
+      dma_1k(src, dst + jj * 1024, lane);
+    }
+  };
+  f4 dw[MTB][NTW];
+  float bs[MTB];
+#pragma unroll
+  for (int m = 0; m < MTB; ++m) {
+    bs[m] = 0.f;
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) dw[m][n] = f4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int u0 = 0; u0 < RU - 1; ++u0) issue_unit(u0);
+  // address of this lane's transposed-read element inside a quantity's NS-block region:
+  // rows = points 8 (qk & 1) + (i16 >> 2) (+4 for the second read), column quad = i16 & 3, at fixed (s, h)
+  const int tr_lane = (8 * (qk & 1) + (i16 >> 2)) * 64 + (i16 & 3) * 16;
+  const int cq_lane = qk >> 1;                     // which of the unit's two quantities this lane group contracts
+  for (int64_t u = 0; u < U; ++u) {
+    if (u + RU - 1 > U) wait_vm<0>();              // fewer than RU - 2 younger units exist: drain
+    else wait_vm<(RU - 2) * UDMA>();
+    __builtin_amdgcn_s_barrier();
+    issue_unit(u + RU - 1);
+    const char* ub = smem + (int)(u % RU) * UNIT;
+    const int ku = (int)(u % KU);
+    const bool qlive = 2 * ku + cq_lane < K1;      // odd K1: the padded quantity contributes nothing
+    const char* zb = ub + cq_lane * (NS * 1024) + tr_lane;
+    const char* ab = ub + HALF + cq_lane * (NS * 1024) + tr_lane;
+    bf8 za[MTB];
+#pragma unroll
+    for (int m = 0; m < MTB; ++m) {
+      const int MT = wave * MTB + m;
+      bf8 v = tr_operand(zb + (MT >> 1) * 1024 + (MT & 1) * 8);
+      if (!qlive) v = bf8{0, 0, 0, 0, 0, 0, 0, 0};
+      za[m] = v;
+      if (ku == 0 && qk < 2) {                     // bias gradient: sum over points of zbar's value quantity
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sacc += bf2f(v[j]);
+        bs[m] += sacc;
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+      const bf8 bb = tr_operand(ab + (n >> 1) * 1024 + (n & 1) * 8);
+#pragma unroll
+      for (int m = 0; m < MTB; ++m) dw[m][n] = mfma32(za[m], bb, dw[m][n]);
+    }
+  }
+  wait_vm<0>();
+  // one flush per wave into the flat torch-layout gradient: dW_l (out, in) row-major, then b_l
+  float* dWl = P.dW + P.w_off1 + (int64_t)li * P.w_per;
+  float* dbl = dWl + (int64_t)P.W * P.W;
+#pragma unroll
+  for (int m = 0; m < MTB; ++m) {
+    const int MT = wave * MTB + m;
+#pragma unroll
+    for (int n = 0; n < NTW; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * MT + 4 * qk + r, col = 16 * n + i16;
+        if (row < P.W && col < P.W)
+          __hip_atomic_fetch_add(dWl + (int64_t)row * P.W + col, dw[m][n][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    float tsum = bs[m];                            // lanes (i16, qk = 0, 1) hold points 0-7 / 8-15 of unit 16 MT + i16
+    tsum += __shfl_xor(tsum, 16, 64);
+    const int row = 16 * MT + i16;
+    if (qk == 0 && row < P.W) __hip_atomic_fetch_add(dbl + row, tsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <int NTW> int launch_chain_fwd(int K1, const ChainParams& P, int grid, hipStream_t s);
+template <int NTW> int launch_chain_bwd(int K1, const ChainParams& P, int grid, hipStream_t s);
+template <int NTW> int launch_chain_wgrad(int K1, const ChainParams& P, int grid, hipStream_t s);
+
+}  // namespace pinn

@@ -1,7 +1,7 @@
 // pinn_wide.hip — host side of the wide MFMA engine (64 < W <= 256): weight packing, chunked
 // point loop, per-layer launches.  Kernels: wide_kernel.h.
 #include <type_traits>
-#include "wide_kernel.h"
+#include "chain_kernel.h"
 
 namespace pinn {
 
@@ -21,21 +21,27 @@ int64_t al256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 
 int cus() { return device_cu_count(); }
 
-constexpr int64_t ACT_BUDGET_BYTES = (int64_t)6 << 30;   // activation workspace per chunk
+constexpr int64_t ACT_BUDGET_BYTES = (int64_t)6 << 30;   // activation workspace per chunk (fp32 mode)
+// bf16 mode (chain kernels): 2L + 1 bf16 jets per chunk, and the weight-gradient kernel flushes its registers
+// once per chunk and workgroup — chunks are as large as a 288 GB part comfortably allows
+constexpr int64_t CHAIN_BUDGET_BYTES = (int64_t)56 << 30;
 
 struct WLayout {
   int64_t chunk_pts, chunk_tiles, n_chunks;
   int64_t wp, wtp, bp, wp16, wtp16, act, act_stride, gA, gB, gZ, gout, sums, total;
+  int64_t wf, wtf, jA, jZ, jGL, jG1, jet_stride;   // bf16 mode: packed fragments, chain-layout jets (byte offsets; jet_stride in bytes)
   int grid;
 };
 WLayout wlayout(const Net& n, const WGeo& g, int64_t N) {
   WLayout w;
   const int K1 = 1 + PINN_MAX_DIRS;
-  // L jets + 2 adjoint buffers (+1 zbar buffer in bf16 mode, where two waves share a tile)
-  const int64_t per_pt = (int64_t)K1 * g.WP * 4 * (n.L + 2 + (n.prec == PINN_PREC_BF16 ? 1 : 0)) + (int64_t)K1 * 16 * 4;
+  const bool chain = n.prec == PINN_PREC_BF16;
+  // fp32 mode: L jets + 2 adjoint buffers, fp32.  bf16 mode: a_1..a_L, zbar_1..zbar_{L-1}, abar_L, abar_1 in bf16.
+  const int64_t per_pt = chain ? (int64_t)K1 * g.WP * 2 * (2 * n.L + 1) + (int64_t)K1 * 16 * 4
+                               : (int64_t)K1 * g.WP * 4 * (n.L + 2) + (int64_t)K1 * 16 * 4;
   // whole number of tiles per wave in every full chunk (no tail imbalance): multiple of waves * 16 points
   const int64_t quantum = (int64_t)cus() * WIDE_WAVES * 16;
-  int64_t cp = ACT_BUDGET_BYTES / per_pt;
+  int64_t cp = (chain ? CHAIN_BUDGET_BYTES : ACT_BUDGET_BYTES) / per_pt;
   cp = (cp / quantum) * quantum;
   if (cp < quantum) cp = quantum;
   const int64_t npad = ((N + 15) / 16) * 16;
@@ -49,10 +55,23 @@ WLayout wlayout(const Net& n, const WGeo& g, int64_t N) {
   w.wp16 = off; off += al256((int64_t)g.PW * 2);
   w.wtp16 = off; off += al256((int64_t)g.PW * 2);
   w.act_stride = al256(w.chunk_tiles * K1 * g.NTW * 256 * 4);
-  w.act = off; off += w.act_stride * n.L;
-  w.gA = off; off += w.act_stride;
-  w.gB = off; off += w.act_stride;
-  w.gZ = off; off += (n.prec == PINN_PREC_BF16) ? w.act_stride : 0;
+  w.act = w.gA = w.gB = w.gZ = 0;
+  w.wf = w.wtf = w.jA = w.jZ = w.jGL = w.jG1 = w.jet_stride = 0;
+  if (!chain) {
+    w.act = off; off += w.act_stride * n.L;
+    w.gA = off; off += w.act_stride;
+    w.gB = off; off += w.act_stride;
+  } else {
+    const int64_t frag = al256((int64_t)(n.L - 1) * g.WP * g.WP * 2 * 2);   // hi + lo bf16 per hidden matrix
+    w.wf = off; off += frag;
+    w.wtf = off; off += frag;
+    w.jet_stride = al256(w.chunk_tiles * K1 * g.NTW * 256 * 2);
+    w.jA = off; off += w.jet_stride * n.L;
+    w.jZ = off; off += w.jet_stride * (n.L > 1 ? n.L - 1 : 0);
+    w.jGL = off; off += w.jet_stride;
+    if (n.L > 1) { w.jG1 = off; off += w.jet_stride; }
+    else w.jG1 = w.jGL;                                  // no hidden matrix: abar_1 is abar_L
+  }
   w.gout = off; off += al256(w.chunk_tiles * K1 * 256 * 4);
   w.sums = off; off += al256(w.n_chunks * w.grid * MAX_SUMS * 4);
   w.total = off;
@@ -98,6 +117,39 @@ __global__ void k_wide_reduce_sums(const float* __restrict__ wg_sums, int64_t ro
   if (threadIdx.x == 0 && blockIdx.x < nt) out[blockIdx.x] = (float)red[0];
 }
 
+// Hidden matrices W_1 .. W_{L-1} -> MFMA fragment order for the chain kernels (chain_kernel.h), hi + lo bf16:
+//   Wf [li][MT][hl][s][lane][j] = W_l[16 MT + m][n(s, qk, j)]        (forward: rows = output units)
+//   WTf[li][MT][hl][s][lane][j] = W_l[n(s, qk, j)][16 MT + m]        (reverse: rows = input units)
+// lane = (m = lane & 15, qk = lane >> 4), n(s, qk, j) = 32 s + 16 (j >> 2) + 4 qk + (j & 3): the k index is
+// permuted inside each k-step so that two accumulator tiles are the next B operand as they stand.
+__global__ void k_chain_pack(Net n, int NTW, const float* __restrict__ params, unsigned short* __restrict__ Wf,
+                             unsigned short* __restrict__ WTf) {
+  const int NS = NTW / 2;
+  const int64_t per_layer = (int64_t)NTW * NS * 512;            // (MT, s, lane, j) combinations
+  const int64_t total = (int64_t)(n.L - 1) * per_layer;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int li = (int)(e / per_layer);
+  int64_t r = e % per_layer;
+  const int MT = (int)(r / (NS * 512)); r %= NS * 512;
+  const int s = (int)(r / 512); r %= 512;
+  const int lane = (int)(r / 8), j = (int)(r % 8);
+  const int m = lane & 15, qk = lane >> 4;
+  const int row = 16 * MT + m, kk = 32 * s + 16 * (j >> 2) + 4 * qk + (j & 3);
+  const int W = n.W;
+  const float* Wl = params + n.w_off(li + 1);
+  const bool in = row < W && kk < W;
+  const float wf = in ? Wl[(int64_t)row * W + kk] : 0.f;
+  const float wt = in ? Wl[(int64_t)kk * W + row] : 0.f;
+  const int64_t slab = ((int64_t)li * NTW + MT) * (2 * NS * 512);
+  const int64_t o_hi = slab + (int64_t)s * 512 + lane * 8 + j, o_lo = o_hi + (int64_t)NS * 512;
+  const __bf16 fh = (__bf16)wf, th = (__bf16)wt;
+  Wf[o_hi] = __builtin_bit_cast(unsigned short, fh);
+  Wf[o_lo] = __builtin_bit_cast(unsigned short, (__bf16)(wf - (float)fh));
+  WTf[o_hi] = __builtin_bit_cast(unsigned short, th);
+  WTf[o_lo] = __builtin_bit_cast(unsigned short, (__bf16)(wt - (float)th));
+}
+
 template <int NTW>
 int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float* params, const float* X, int64_t N,
           float* Y, float* dY, char* base, const WLayout& w, hipStream_t s) {
@@ -135,11 +187,17 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
   hipLaunchKernelGGL(k_wide_pack, dim3((packN + 255) / 256), dim3(256), 0, s, n, g.WP, params, (float*)(base + w.wp),
                      (float*)(base + w.wtp), (float*)(base + w.bp), (unsigned short*)(base + w.wp16),
                      (unsigned short*)(base + w.wtp16), g.PW, g.PB);
+  const bool chain = prec == PINN_PREC_BF16;
+  const int nh = n.L - 1;                                  // hidden (W x W) matrices
+  if (chain && nh > 0) {
+    const int64_t total = (int64_t)nh * NTW * (NTW / 2) * 512;
+    hipLaunchKernelGGL(k_chain_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, n, NTW, params,
+                       (unsigned short*)(base + w.wf), (unsigned short*)(base + w.wtf));
+  }
   auto woff = [&](int l) { return l == 0 ? 0 : g.WP * 16 + (l - 1) * g.WP * g.WP; };
   auto act_l = [&](int l) { return (float*)(base + w.act + (int64_t)(l - 1) * w.act_stride); };   // a_l, l = 1..L
   float* gA = (float*)(base + w.gA);
   float* gB = (float*)(base + w.gB);
-  float* gZ = (float*)(base + w.gZ);
   float* gout = (float*)(base + w.gout);
   const int K1 = n.K1, L = n.L;
   const int64_t total_tiles = (N + 15) / 16;
@@ -155,6 +213,45 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
     // zero this chunk's rows of the partial-sum table (a smaller grid leaves rows untouched)
     if (hipMemsetAsync(P.wg_sums + (int64_t)Lp.sums_slot * MAX_SUMS, 0, (size_t)w.grid * MAX_SUMS * 4, s) != hipSuccess) {
       set_error("hipMemsetAsync failed"); return PINN_ERR_LAUNCH;
+    }
+    if (chain) {
+      // ---- bf16 mode: first / last layer on this file's kernels (fp32 MFMA on the thin matrices, chain-layout
+      // bf16 jets), the L - 1 hidden matrices on the three chain kernels (chain_kernel.h) ----
+      ChainParams C;
+      memset(&C, 0, sizeof(C));
+      C.L = L; C.n_tiles = Lp.n_tiles; C.jet_stride = w.jet_stride / 2;
+      C.Wf = (const unsigned short*)(base + w.wf); C.WTf = (const unsigned short*)(base + w.wtf); C.bias = Bp;
+      C.A = (unsigned short*)(base + w.jA); C.Z = (unsigned short*)(base + w.jZ);
+      C.GL = (unsigned short*)(base + w.jGL); C.G1 = (unsigned short*)(base + w.jG1);
+      C.dW = grad ? rq->grad : nullptr; C.spill = grad ? 1 : 0; C.W = n.W;
+      C.w_off1 = n.w_off(1); C.w_per = (int64_t)n.W * n.W + n.W;
+      auto jetA = [&](int l) { return (float*)(base + w.jA + (int64_t)(l - 1) * w.jet_stride); };   // a_l, l = 1..L
+      const int cgrid = (int)((Lp.n_tiles + CHAIN_WAVES - 1) / CHAIN_WAVES < w.grid ? (Lp.n_tiles + CHAIN_WAVES - 1) / CHAIN_WAVES : w.grid);
+      Lp.W = Wp; Lp.b = Bp; Lp.out_act = jetA(1);
+      rc = launch_wide_fwd<NTW>(0, K1, prec, false, P, Lp, grid, s); if (rc) break;
+      if (nh > 0) { rc = launch_chain_fwd<NTW>(K1, C, cgrid, s); if (rc) break; }
+      Lp.W = Wp + woff(L); Lp.b = Bp + L * g.WP; Lp.in_act = jetA(L); Lp.out_act = nullptr; Lp.g_out = gout;
+      rc = launch_wide_fwd<NTW>(2, K1, prec, grad, P, Lp, grid, s); if (rc) break;
+      if (!grad) continue;
+      // output layer: dW_L = G . a_L^T ; abar_L = W_L^T G (bf16, chain layout)
+      Lp.g_in = gout; Lp.in_act = jetA(L); Lp.in_d = n.in_dim(L); Lp.out_d = n.out_dim(L);
+      Lp.dW = rq->grad + n.w_off(L); Lp.db = rq->grad + n.b_off(L);
+      rc = launch_wide_wgrad<NTW>(2, K1, prec, P, Lp, w.grid, s); if (rc) break;
+      Lp.W = WTp + woff(L); Lp.g_out = (float*)C.GL;
+      rc = launch_wide_bwd<NTW>(2, K1, prec, P, Lp, grid, s); if (rc) break;
+      if (nh > 0) { rc = launch_chain_bwd<NTW>(K1, C, cgrid, s); if (rc) break; }
+      // first layer: zbar_0 = adjoint(abar_1, a_1), in place over abar_1; dW_0 = zbar_0 . (x, e_j)^T
+      Lp.g_in = (float*)C.G1; Lp.in_act = jetA(1); Lp.g_out = nullptr; Lp.W = nullptr; Lp.z_out = (float*)C.G1;
+      rc = launch_wide_bwd<NTW>(0, K1, prec, P, Lp, grid, s); if (rc) break;
+      Lp.g_in = (float*)C.G1; Lp.in_act = nullptr; Lp.in_d = n.in_dim(0); Lp.out_d = n.out_dim(0);
+      Lp.dW = rq->grad + n.w_off(0); Lp.db = rq->grad + n.b_off(0);
+      rc = launch_wide_wgrad<NTW>(0, K1, prec, P, Lp, w.grid, s); if (rc) break;
+      if (nh > 0) {
+        C.n_slices = w.grid / nh > 0 ? w.grid / nh : 1;
+        if ((int64_t)C.n_slices > Lp.n_tiles) C.n_slices = (int)Lp.n_tiles;
+        rc = launch_chain_wgrad<NTW>(K1, C, C.n_slices * nh, s); if (rc) break;
+      }
+      continue;
     }
     // ---- forward ----
     Lp.W = Wp; Lp.W16 = Wp16; Lp.b = Bp; Lp.out_act = act_l(1);
@@ -179,7 +276,7 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
     for (int l = L - 1; l >= 1; --l) {
       // zbar_l (in place over gcur) and abar_l = W_l^T zbar_l
       Lp.W = WTp + woff(l); Lp.W16 = WTp16 + woff(l); Lp.g_in = gcur; Lp.in_act = act_l(l + 1); Lp.g_out = gnext;
-      float* zdst = (prec == PINN_PREC_BF16) ? gZ : gcur;   // fp32: one wave per tile -> in place
+      float* zdst = gcur;   // one wave per tile -> zbar goes back in place over the incoming adjoint
       Lp.z_out = zdst;
       rc = launch_wide_bwd<NTW>(1, K1, prec, P, Lp, grid, s); if (rc) break;
       Lp.g_in = zdst; Lp.in_act = act_l(l); Lp.in_d = n.in_dim(l); Lp.out_d = n.out_dim(l);

@@ -67,21 +67,38 @@ __device__ __forceinline__ bf16x4 load_w16(const unsigned short* __restrict__ W1
 constexpr int FMT_IN16 = 1;    // Lp.in_act holds bf16
 constexpr int FMT_GIN16 = 2;   // Lp.g_in holds bf16
 constexpr int FMT_OUT16 = 4;   // what the kernel writes (out_act / g_out / z_out) is bf16
+// "chain layout" (chain_kernel.h): bf16 jets of the bf16-mode engine, [tile][quantity][k-step s][point][32 units];
+// the first / last layer's kernels of this file read and write the chain kernels' buffers in it
+constexpr int FMT_IN_NEW = 8, FMT_GIN_NEW = 16, FMT_OUT_NEW = 32;
 __device__ __forceinline__ f4 from_bf16x4(bf16x4 v) {
   f4 o;
 #pragma unroll
   for (int i = 0; i < 4; ++i) o[i] = __builtin_bit_cast(float, (unsigned)(unsigned short)v[i] << 16);
   return o;
 }
-// block = one 16x16 tile of one quantity (256 elements), fragment-native: element lane*4 + r
-template <bool H>
+// block = one 16x16 tile of one quantity (256 elements), fragment-native: element lane*4 + r.
+// blk = (tile * K1 + quantity) * NT + MT.  NEWL (bf16 only, NT even): the chain layout — tile MT of a quantity is
+// the h = MT & 1 half of k-step s = MT >> 1: 4 elements at ((tq * NT/2 + s) * 512 + (4p + q) * 8 + 4h.
+template <int NT>
+__device__ __forceinline__ int64_t jet_off_new(int64_t blk, int lane) {
+  const int64_t tq = blk / NT;
+  const int MT = (int)(blk % NT);
+  return (tq * (NT / 2) + (MT >> 1)) * 512 + (4 * (lane & 15) + (lane >> 4)) * 8 + (MT & 1) * 4;
+}
+template <bool H, bool NEWL = false, int NT = 2>
 __device__ __forceinline__ f4 jet_ld(const float* base, int64_t blk, int lane) {
-  if constexpr (H) return from_bf16x4(*reinterpret_cast<const bf16x4*>(reinterpret_cast<const unsigned short*>(base) + blk * 256 + lane * 4));
+  if constexpr (NEWL) {
+    static_assert(!NEWL || (H && NT % 2 == 0), "chain layout: bf16 jets of whole k-steps");
+    return from_bf16x4(*reinterpret_cast<const bf16x4*>(reinterpret_cast<const unsigned short*>(base) + jet_off_new<NT>(blk, lane)));
+  } else if constexpr (H) return from_bf16x4(*reinterpret_cast<const bf16x4*>(reinterpret_cast<const unsigned short*>(base) + blk * 256 + lane * 4));
   else return *reinterpret_cast<const f4*>(base + blk * 256 + lane * 4);
 }
-template <bool H>
+template <bool H, bool NEWL = false, int NT = 2>
 __device__ __forceinline__ void jet_st(float* base, int64_t blk, int lane, f4 v) {
-  if constexpr (H) *reinterpret_cast<bf16x4*>(reinterpret_cast<unsigned short*>(base) + blk * 256 + lane * 4) = to_bf16x4(v);
+  if constexpr (NEWL) {
+    static_assert(!NEWL || (H && NT % 2 == 0), "chain layout: bf16 jets of whole k-steps");
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<unsigned short*>(base) + jet_off_new<NT>(blk, lane)) = to_bf16x4(v);
+  } else if constexpr (H) *reinterpret_cast<bf16x4*>(reinterpret_cast<unsigned short*>(base) + blk * 256 + lane * 4) = to_bf16x4(v);
   else *reinterpret_cast<f4*>(base + blk * 256 + lane * 4) = v;
 }
 
@@ -180,7 +197,7 @@ __global__ __launch_bounds__(WIDE_THREADS * HV, HV) void k_wide_fwd(const FusedP
       for (int c = 0; c < K1; ++c)
 #pragma unroll
         for (int j = 0; j < CH; ++j)
-          Bc[c][j] = jet_ld<(FMT & FMT_IN16) != 0>(Lp.in_act, (t * K1 + c) * NTI + kc + j, lane);
+          Bc[c][j] = jet_ld<(FMT & FMT_IN16) != 0, (FMT & FMT_IN_NEW) != 0, (NTI > 1 ? NTI : 2)>(Lp.in_act, (t * K1 + c) * NTI + kc + j, lane);
     };
     for (int kc = 0; kc < NTI; kc += CH) {
       f4 B[K1][CH];
@@ -200,7 +217,7 @@ __global__ __launch_bounds__(WIDE_THREADS * HV, HV) void k_wide_fwd(const FusedP
       for (int c = 0; c < K1; ++c)
 #pragma unroll
         for (int MT = 0; MT < NTO; ++MT)
-          jet_st<(FMT & FMT_OUT16) != 0>(Lp.out_act, (t * K1 + c) * NTO_ALL + hf * NTO + MT, lane, acc[c][MT]);
+          jet_st<(FMT & FMT_OUT16) != 0, (FMT & FMT_OUT_NEW) != 0, (NTO_ALL > 1 ? NTO_ALL : 2)>(Lp.out_act, (t * K1 + c) * NTO_ALL + hf * NTO + MT, lane, acc[c][MT]);
     } else {
       static_assert(!LAST || NTO == 1, "the output layer has one (padded) tile");
       f4 (&out)[K1][1] = acc;
@@ -261,14 +278,14 @@ __global__ __launch_bounds__(WIDE_THREADS * HV, HV) void k_wide_bwd(const FusedP
       for (int c = 0; c < K1; ++c)
 #pragma unroll
         for (int j = 0; j < CH; ++j)
-          g[c][j] = jet_ld<(FMT & FMT_GIN16) != 0>(HV == 1 ? Lp.g_in : gin_p, (t * K1 + c) * NTK + kc + j, lane);
+          g[c][j] = jet_ld<(FMT & FMT_GIN16) != 0, (FMT & FMT_GIN_NEW) != 0, (NTK > 1 ? NTK : 2)>(HV == 1 ? Lp.g_in : gin_p, (t * K1 + c) * NTK + kc + j, lane);
       if constexpr (HIDDEN) {
         f4 ao[K1][CH];
 #pragma unroll
         for (int c = 0; c < K1; ++c)
 #pragma unroll
           for (int j = 0; j < CH; ++j)
-            ao[c][j] = jet_ld<(FMT & FMT_IN16) != 0>(act_p, (t * K1 + c) * NTK + kc + j, lane);
+            ao[c][j] = jet_ld<(FMT & FMT_IN16) != 0, (FMT & FMT_IN_NEW) != 0, (NTK > 1 ? NTK : 2)>(act_p, (t * K1 + c) * NTK + kc + j, lane);
         activate_adjoint<ACT, CH, K1>(g, ao);
         // HV == 1: in place through the SAME pointer the loads use (the compiler then knows the store
         // cannot alias the next chunk's loads); HV == 2: separate buffer, written by one of the two waves
@@ -282,7 +299,7 @@ __global__ __launch_bounds__(WIDE_THREADS * HV, HV) void k_wide_bwd(const FusedP
             for (int c = 0; c < K1; ++c)
 #pragma unroll
               for (int j = 0; j < CH; ++j)
-                jet_st<(FMT & FMT_OUT16) != 0>(zdst, (t * K1 + c) * NTK + kc + j, lane, g[c][j]);
+                jet_st<(FMT & FMT_OUT16) != 0, (FMT & FMT_OUT_NEW) != 0 && (NTK > 1), (NTK > 1 ? NTK : 2)>(zdst, (t * K1 + c) * NTK + kc + j, lane, g[c][j]);
           }
         }
       };
@@ -294,7 +311,7 @@ __global__ __launch_bounds__(WIDE_THREADS * HV, HV) void k_wide_bwd(const FusedP
       for (int c = 0; c < K1; ++c)
 #pragma unroll
         for (int MT = 0; MT < NTO; ++MT)
-          jet_st<(FMT & FMT_OUT16) != 0>(gout_p, (t * K1 + c) * NTO_ALL + hf * NTO + MT, lane, acc[c][MT]);
+          jet_st<(FMT & FMT_OUT16) != 0, (FMT & FMT_OUT_NEW) != 0, (NTO_ALL > 1 ? NTO_ALL : 2)>(gout_p, (t * K1 + c) * NTO_ALL + hf * NTO + MT, lane, acc[c][MT]);
     }
   }
 }
@@ -336,10 +353,10 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_wgrad(const FusedParam
     auto fetch = [&](int64_t t, int c) {
 #pragma unroll
       for (int MT = 0; MT < MTB; ++MT)
-        rz[MT] = jet_ld<(FMT & FMT_GIN16) != 0>(Lp.g_in, (t * K1 + c) * NTM + rb * MTB + MT, lane);
+        rz[MT] = jet_ld<(FMT & FMT_GIN16) != 0, (FMT & FMT_GIN_NEW) != 0, (NTM > 1 ? NTM : 2)>(Lp.g_in, (t * K1 + c) * NTM + rb * MTB + MT, lane);
 #pragma unroll
       for (int i = 0; i < APW; ++i)
-        ra[i] = jet_ld<(FMT & FMT_IN16) != 0>(Lp.in_act, (t * K1 + c) * NTN + wave * APW + i, lane);
+        ra[i] = jet_ld<(FMT & FMT_IN16) != 0, (FMT & FMT_IN_NEW) != 0, (NTN > 1 ? NTN : 2)>(Lp.in_act, (t * K1 + c) * NTN + wave * APW + i, lane);
     };
     if (gw < Lp.n_tiles) fetch(gw, 0);
     int buf = 0;
@@ -397,7 +414,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_wgrad(const FusedParam
   auto fetch = [&](int64_t t, int c) {
 #pragma unroll
     for (int MT = 0; MT < MTB; ++MT)
-      rz[MT] = jet_ld<(FMT & FMT_GIN16) != 0>(Lp.g_in, (t * K1 + c) * NTM + rb * MTB + MT, lane);
+      rz[MT] = jet_ld<(FMT & FMT_GIN16) != 0, (FMT & FMT_GIN_NEW) != 0, (NTM > 1 ? NTM : 2)>(Lp.g_in, (t * K1 + c) * NTM + rb * MTB + MT, lane);
     if constexpr (FIRST) {
       const int64_t pt = (Lp.tile0 + t) * 16 + p;
       f4 b0[K1][1];
@@ -407,7 +424,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_wgrad(const FusedParam
     } else {
 #pragma unroll
       for (int NT = 0; NT < NTN; ++NT)
-        ra[NT] = jet_ld<(FMT & FMT_IN16) != 0>(Lp.in_act, (t * K1 + c) * NTN + NT, lane);
+        ra[NT] = jet_ld<(FMT & FMT_IN16) != 0, (FMT & FMT_IN_NEW) != 0, (NTN > 1 ? NTN : 2)>(Lp.in_act, (t * K1 + c) * NTN + NT, lane);
     }
   };
   // (fp32 mode: the 256 MFMAs per quantity leave no registers for the look-ahead — measured 30 %
