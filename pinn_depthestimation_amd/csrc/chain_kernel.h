@@ -43,13 +43,27 @@ typedef short sh4 __attribute__((ext_vector_type(4)));
 
 constexpr int CHAIN_WAVES = 4;
 constexpr int CHAIN_THREADS = CHAIN_WAVES * 64;
-constexpr int CHAIN_RING = 6;              // weight slabs in the LDS ring (fwd / bwd chain)
+constexpr int CHAIN_RING = 6;              // weight slabs in the LDS ring of the reverse chain (next to its prefetch areas)
+#ifndef PINN_CHAIN_RING_FWD
+#define PINN_CHAIN_RING_FWD 8
+#endif
+constexpr int CHAIN_RING_FWD = PINN_CHAIN_RING_FWD;   // ... of the forward chain
+// Weight precision of the REVERSE chain.  Measured on the reference's 12 x 256 golden (G10): rounding the weights to
+// bf16 in the FORWARD pass moves the gradient by 1.2e-1 (the loss is evaluated at a shifted point of a stiff
+// surface) — the forward chain always multiplies by hi + lo.  Rounding them in the reverse pass alone is a random,
+// averaging error: gradient 5.2e-3 instead of 3.3e-3 for 7 % of the step (2^20 points: 40.0 vs 42.9 ms).  Default 1
+// (hi + lo in both directions): the stated bf16 tolerance of this engine is 5e-3.
+#ifndef PINN_CHAIN_BWD_LO
+#define PINN_CHAIN_BWD_LO 1
+#endif
 constexpr int WG_UNITS = 4;                // LDS ring slots of the weight-gradient kernel (half tiles)
 
 struct ChainParams {
   int L;                      // hidden layers of the network (L - 1 hidden W x W matrices: layers 1 .. L-1)
   int64_t n_tiles;            // tiles in this chunk
   int64_t jet_stride;         // elements (bf16) between consecutive layers' jets
+  int64_t w_plane;            // bytes between the 1 KB pieces of one weight slab (see k_chain_pack: pieces are spread
+                              // over memory so that the CUs of an XCD, reading the same slab together, load many L2 channels)
   const unsigned short* Wf;   // packed weight fragments, layers 1 .. L-1 (fwd) — see k_chain_pack
   const unsigned short* WTf;  // packed transposed weight fragments (bwd)
   const float* bias;          // padded biases, fp32: layer l at bias + l * WP
@@ -62,18 +76,36 @@ struct ChainParams {
   int W;                      // real hidden width
   int n_slices;               // wgrad: point slices per layer
   int64_t w_off1, w_per;      // flat offsets: W_1 at w_off1, W_{l+1} - W_l = w_per; b_l at w_off(l) + W*W
+  unsigned long long* diag;   // -DPINN_CHAIN_DIAG builds only: per-phase cycle sums of workgroup 0 / wave 0
 };
 
+// Diagnostic build (-DPINN_CHAIN_DIAG, tools/chain_diag.sh): s_memtime stamps per phase, summed by one wave.
+// Stamps serialise the instruction stream: read the SHARES, not the total.
+#ifdef PINN_CHAIN_DIAG
+#define CHAIN_STAMP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); dg[i] += t_ - tprev; tprev = t_; } while (0)
+#define CHAIN_DIAG_BEGIN unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter()
+#define CHAIN_DIAG_END(P) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (P).diag) for (int i_ = 0; i_ < 8; ++i_) (P).diag[i_] = dg[i_]; } while (0)
+#else
+#define CHAIN_STAMP(i) do { } while (0)
+#define CHAIN_DIAG_BEGIN do { } while (0)
+#define CHAIN_DIAG_END(P) do { } while (0)
+#endif
+
+#ifdef PINN_CHAIN_EXP_NOMFMA   // timing experiment only (results are garbage): how fast do the weight copies run alone?
+__device__ __forceinline__ f4 mfma32(bf8 a, bf8 b, f4 c) { asm volatile("" ::"v"(a), "v"(b)); return c; }
+#else
 __device__ __forceinline__ f4 mfma32(bf8 a, bf8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // 1 KB LDS-DMA copy: lane i moves 16 bytes from src + 16 i to lds_dst + 16 i (lds_dst wave-uniform)
+template <int AUX = 0>
 __device__ __forceinline__ void dma_1k(const void* src, void* lds_dst, int lane) {
   __builtin_amdgcn_global_load_lds(
-      (const void __attribute__((address_space(1)))*)((const char*)src + lane * 16),
-      (void __attribute__((address_space(3)))*)lds_dst, 16, 0, 0);
+      (const void __attribute__((address_space(1)))*)((const char*)src + (unsigned)lane * 16u),
+      (void __attribute__((address_space(3)))*)lds_dst, 16, 0, AUX);
 }
 
 __device__ __forceinline__ float bf2f(__bf16 v) { return (float)v; }
@@ -86,11 +118,22 @@ typedef unsigned u4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t jet_rsrc(const void* tile_base, int bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(tile_base), 0, bytes, 0x00020000);
 }
+// Cache policy of the jet streams.  The chain kernels re-read the SAME packed weights (2.8 MB per direction at
+// 12 x 256: they fit an XCD's 4 MB L2) once per tile batch, while ~50 MB of jets per XCD pass through that L2 in
+// between: with default-policy jet traffic the weight copies ran at the beyond-L2 LDS-DMA rate (~25 GB/s per CU,
+// = the 16 KB of every GEMM step: the steps were bound by them, not by their 64 MFMAs).  Jets are written once
+// and read once much later: stores go out write-through / no L2 allocation (sc1), loads are non-temporal (nt).
+#ifndef PINN_CHAIN_JET_ST_AUX
+#define PINN_CHAIN_JET_ST_AUX 16   // sc1
+#endif
+#ifndef PINN_CHAIN_JET_LD_AUX
+#define PINN_CHAIN_JET_LD_AUX 2    // nt
+#endif
 __device__ __forceinline__ bf8 ld_blk(__amdgpu_buffer_rsrc_t r, unsigned lane_off, int blk_off) {
-  return __builtin_bit_cast(bf8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_off, blk_off, 0));
+  return __builtin_bit_cast(bf8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_off, blk_off, PINN_CHAIN_JET_LD_AUX));
 }
 __device__ __forceinline__ void st_blk(__amdgpu_buffer_rsrc_t r, unsigned lane_off, int blk_off, bf8 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, (int)lane_off, blk_off, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, (int)lane_off, blk_off, PINN_CHAIN_JET_ST_AUX);
 }
 
 // a wave-uniform 64-bit value the compiler cannot prove uniform (derived from threadIdx): moved to SGPRs so
@@ -109,32 +152,47 @@ __device__ __forceinline__ float tanh_bf(float x) {
 }
 
 
+// Workgroups that share an XCD (blockIdx.x % 8, observed dispatch: speed only) all start on the same weight slab;
+// `chain_stagger` delays each by its index inside the XCD times ~one GEMM step, so that at any time the XCD's CUs
+// ask its L2 for DIFFERENT slabs instead of queueing 32-deep on the same lines.
+#ifndef PINN_CHAIN_STAGGER
+#define PINN_CHAIN_STAGGER 24      // s_sleep(64) units of 64 clocks... x 64 cycles per workgroup index inside its XCD (0 = off)
+#endif
+__device__ __forceinline__ void chain_stagger() {
+  if (PINN_CHAIN_STAGGER > 0) {
+    const int k = (blockIdx.x >> 3) & 31;
+    for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(PINN_CHAIN_STAGGER);
+  }
+}
+
 // The weight ring of the two chain kernels.  Slabs are consumed in a fixed order (tile batch, layer, output tile);
 // `next` walks that order one slab ahead of the R - 1 in flight.  Everything is wave-uniform.
 template <int NTW, int SLAB, int R, bool DESCENDING>
 struct SlabRing {
-  const char* base; char* lds; int nh, wave, lane;
+  const char* base; char* lds; int nh, wave, lane; int64_t plane;
   int64_t issued, total;      // slabs issued so far / slabs this workgroup consumes
   int li, MT, slot;           // of the next slab to issue
   int cslot;                  // ring slot of the slab being consumed
-  __device__ __forceinline__ void init(const void* w, char* smem, int nh_, int64_t total_, int wave_, int lane_) {
-    base = (const char*)w; lds = smem; nh = nh_; total = total_; wave = wave_; lane = lane_;
+  __device__ __forceinline__ void init(const void* w, int64_t plane_, char* smem, int nh_, int64_t total_, int wave_, int lane_) {
+    base = (const char*)w; plane = plane_; lds = smem; nh = nh_; total = total_; wave = wave_; lane = lane_;
     issued = 0; li = DESCENDING ? nh - 1 : 0; MT = 0; slot = 0; cslot = 0;
   }
   __device__ __forceinline__ void issue() {
     if (issued >= total) return;
     constexpr int QDMA = SLAB / 4 / 1024;
-    const char* src = base + ((int64_t)(li * NTW + MT)) * SLAB + wave * (SLAB / 4);
+    // piece i of slab n lives at  i * plane + n * 1 KB
+    const char* src = base + (int64_t)(wave * QDMA) * plane + ((int64_t)(li * NTW + MT)) * 1024;
     char* dst = lds + slot * SLAB + wave * (SLAB / 4);
 #pragma unroll
-    for (int i = 0; i < QDMA; ++i) dma_1k(src + i * 1024, dst + i * 1024, lane);
+    for (int i = 0; i < QDMA; ++i) dma_1k(src + i * plane, dst + i * 1024, lane);
     ++issued;
     slot = slot + 1 == R ? 0 : slot + 1;
     if (++MT == NTW) { MT = 0; li = DESCENDING ? (li == 0 ? nh - 1 : li - 1) : (li + 1 == nh ? 0 : li + 1); }
   }
   // Before consuming slab number `g` (0-based): its copies (this wave's quarter) have landed once at most the
-  // copies of the R - 2 younger slabs — plus `extra` stores this wave issued after them — are outstanding.
-  // Near the end of the sequence fewer younger slabs exist: drain everything.
+  // copies of the R - 2 younger slabs — plus the EXTRA jet stores this wave is known to have issued after
+  // them (`extra_issued`; vmcnt retires in issue order, so every younger operation must be counted or the wait
+  // is for too much) — are outstanding.  Near the end of the sequence fewer younger slabs exist: drain everything.
   template <int EXTRA>
   __device__ __forceinline__ void wait_landed(int64_t g, bool extra_issued) {
     constexpr int QDMA = SLAB / 4 / 1024;
@@ -147,6 +205,60 @@ struct SlabRing {
   __device__ __forceinline__ void consumed() { cslot = cslot + 1 == R ? 0 : cslot + 1; }
 };
 
+// compile-time loop: body(std::integral_constant<int, I>) for I = 0 .. N-1 (the step index parameterises vmcnt immediates)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& body) {
+  if constexpr (I < N) {
+    body(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(body);
+  }
+}
+
+// Jet stores are SPREAD over the GEMM steps that follow the phase producing them (two 1 KB blocks per step until
+// the K1 * NS blocks are out): the registers they come from are the next GEMM's B operand and stay live anyway,
+// and a burst of K1 * NS KB per wave at the end of the activation phase ran at the CU's store rate (~10 B/clk:
+// 38 % of the forward kernel's cycles, tools/chain_diag.sh) while the matrix pipe idled.
+template <int K1, int NS>
+__host__ __device__ constexpr int chain_stores_at(int step) {   // blocks stored at GEMM step `step` (< 0: none)
+  return step < 0 ? 0 : (K1 * NS - 2 * step >= 2 ? 2 : (K1 * NS - 2 * step > 0 ? K1 * NS - 2 * step : 0));
+}
+// stores younger than slab g's copies when step MT of a layer starts: those of the R - 2 previous steps and of the
+// step that issued slab g (its stores follow its copies).  CUR / PREV: are stores riding on this / the previous
+// layer's steps?
+template <int K1, int NS, int NTW, int R, int MT, bool CUR, bool PREV>
+__host__ __device__ constexpr int chain_younger_stores() {
+  int n = 0;
+  for (int j = 1; j <= R - 1; ++j) {
+    const int st = MT - j;
+    if (st >= 0) n += CUR ? chain_stores_at<K1, NS>(st) : 0;
+    else n += PREV ? chain_stores_at<K1, NS>(NTW + st) : 0;
+  }
+  return n;
+}
+
+// vector-memory operations a wave issues at GEMM steps [m0, m1) of the reverse chain besides prefetch copies
+template <int K1, int NS, int QD>
+__host__ __device__ constexpr int chain_ops_in_steps(int m0, int m1) {
+  int n = 0;
+  for (int m = m0; m < m1; ++m) n += QD + chain_stores_at<K1, NS>(m);
+  return n;
+}
+// prefetch copies (two per step from step 0 until the NPF copies are out — early, so that they are old by the time
+// the next phase waits for them) issued at step m / among the R - 1 steps before step MT of the same layer
+template <int NPF>
+__host__ __device__ constexpr int chain_pf_at(int m) {
+  return m < 0 ? 0 : (NPF - 2 * m >= 2 ? 2 : (NPF - 2 * m > 0 ? NPF - 2 * m : 0));
+}
+template <int R, int NPF>
+__host__ __device__ constexpr int chain_younger_prefetch(int MT) {
+  int n = 0;
+  for (int j = 1; j <= R - 1; ++j) n += chain_pf_at<NPF>(MT - j);
+  return n;
+}
+__host__ __device__ constexpr int chain_pf_pieces(int NTW, int K1) {   // k-step pieces of a_l prefetched into LDS
+  return NTW / 2 < NTW / K1 ? NTW / 2 : NTW / K1;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Forward chain.  Weight slab (layer l, output tile MT) = [hi | lo][k-step s][lane][8 bf16]: NS * 2 KB.
 template <int NTW, int K1>
@@ -154,18 +266,26 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_fwd(const ChainParam
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NS = NTW / 2;
   constexpr int SLAB = NS * 2 * 1024;              // bytes
-  constexpr int R = CHAIN_RING;
+  constexpr int R = CHAIN_RING_FWD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4;
   const unsigned lpos = (4u * (lane & 15) + q) * 16u;  // BYTE offset of this lane inside a jet block
   const int nh = P.L - 1;                          // hidden matrices
   const int64_t n_tb = (P.n_tiles + CHAIN_WAVES - 1) / CHAIN_WAVES;
   const int64_t my_tb = (n_tb - blockIdx.x + gridDim.x - 1) / gridDim.x;   // tile batches of this workgroup
+  // biases of every layer in LDS behind the ring: as ordinary global loads next to LDS-DMA traffic each of the 16
+  // bias reads of an activation phase made the compiler drain the whole vector-memory queue (weight copies
+  // included) before its first use
+  float* bias_lds = reinterpret_cast<float*>(smem + R * SLAB);
+  for (int i = threadIdx.x; i < (P.L + 1) * 16 * NTW; i += CHAIN_THREADS) bias_lds[i] = P.bias[i];
+  __syncthreads();
+  chain_stagger();
   SlabRing<NTW, SLAB, R, false> ring;
-  ring.init(P.Wf, smem, nh, my_tb * nh * NTW, wave, lane);
+  ring.init(P.Wf, P.w_plane, smem, nh, my_tb * nh * NTW, wave, lane);
   for (int g0 = 0; g0 < R - 1; ++g0) ring.issue();
   int64_t g = 0;
-  bool stored = false;                             // did this wave issue its K1 * NS jet stores in the last activation?
+  bool burst = false;                              // did this wave just write a_L (K1 * NS stores behind the last GEMM)?
+  CHAIN_DIAG_BEGIN;
   for (int64_t tb = blockIdx.x; tb < n_tb; tb += gridDim.x) {
     int64_t t = tb * CHAIN_WAVES + wave;
     const bool live = t < P.n_tiles;               // wave-uniform; dead waves keep the ring protocol going
@@ -179,16 +299,37 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_fwd(const ChainParam
 #pragma unroll
       for (int s = 0; s < NS; ++s)
         bj[c][s] = ld_blk(a1r, lpos, (c * NS + s) * 1024);
+    CHAIN_STAMP(4);
     for (int l = 1; l <= nh; ++l) {
       f4 acc[K1][NTW];
       zero_tiles<NTW, K1>(acc);
-#pragma unroll
-      for (int MT = 0; MT < NTW; ++MT) {
-        // (the first R - 1 steps of a layer: the activation's stores are younger than slab g's copies)
-        if (MT < R - 1) ring.template wait_landed<K1 * NS>(g, stored);
-        else ring.template wait_landed<0>(g, false);
+      // a_l (= bj, this GEMM's B operand) goes out during this GEMM, two blocks per step; a_1 came from memory
+      const bool st_cur = live && P.spill && l >= 2, st_prev = live && P.spill && l >= 3;
+      const __amdgpu_buffer_rsrc_t dst = jet_rsrc(P.A + (int64_t)(l - 1) * P.jet_stride + tbase, TILE_BYTES);
+      static_for<0, NTW>([&](auto mt_) {
+        constexpr int MT = decltype(mt_)::value;
+        CHAIN_STAMP(2);
+        {
+          constexpr int QD = SLAB / 4 / 1024;
+          constexpr int E11 = chain_younger_stores<K1, NS, NTW, R, MT, true, true>();
+          constexpr int E10 = chain_younger_stores<K1, NS, NTW, R, MT, true, false>();
+          static_assert((R - 2) * QD + E11 <= 63, "vmcnt range");
+          if (l == 1 && MT < R - 1) ring.template wait_landed<K1 * NS>(g, burst);   // (a_L's burst of the previous tile batch)
+          else if (st_cur && st_prev) ring.template wait_landed<E11>(g, true);
+          else if (st_cur) ring.template wait_landed<E10>(g, true);
+          else ring.template wait_landed<0>(g, false);
+        }
+        CHAIN_STAMP(0);
         __builtin_amdgcn_s_barrier();              // every quarter landed; every wave is done with slab g - 1
+        CHAIN_STAMP(1);
         ring.issue();                              // ... whose ring slot is refilled now
+        if (st_cur) {
+#pragma unroll
+          for (int i = 0; i < chain_stores_at<K1, NS>(MT); ++i) {
+            const int idx = 2 * MT + i;
+            st_blk(dst, lpos, idx * 1024, bj[idx / NS][idx % NS]);
+          }
+        }
         const char* sl = ring.consume_ptr();
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -202,12 +343,13 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_fwd(const ChainParam
         }
         ring.consumed();
         ++g;
-      }
+      });
       // activation (dnn.py:36-37): a = tanh(z + b), adot_j = (1 - a^2) zdot_j; packed straight into the next
-      // layer's B operand and written out once for the reverse sweep
-      const float* __restrict__ bl = P.bias + l * (16 * NTW);
-      const __amdgpu_buffer_rsrc_t dst = jet_rsrc(P.A + (int64_t)l * P.jet_stride + tbase, TILE_BYTES);
-      stored = live && (P.spill || l == nh);
+      // layer's B operand.  Only a_L is written here (no GEMM follows it in this kernel).
+      CHAIN_STAMP(2);
+      const float* bl = bias_lds + l * (16 * NTW);
+      const __amdgpu_buffer_rsrc_t dstL = jet_rsrc(P.A + (int64_t)l * P.jet_stride + tbase, TILE_BYTES);
+      burst = live && l == nh;
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         float o[K1][8];
@@ -229,12 +371,14 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_fwd(const ChainParam
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = (__bf16)o[c][j];
           bj[c][s] = v;
-          if (stored) st_blk(dst, lpos, (c * NS + s) * 1024, v);
+          if (burst) st_blk(dstL, lpos, (c * NS + s) * 1024, v);
         }
       }
+      CHAIN_STAMP(3);
     }
   }
   wait_vm<0>();
+  CHAIN_DIAG_END(P);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -245,18 +389,32 @@ template <int NTW, int K1>
 __global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_bwd(const ChainParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NS = NTW / 2;
-  constexpr int SLAB = NS * 2 * 1024;
+  constexpr bool LO = PINN_CHAIN_BWD_LO != 0;
+  constexpr int SLAB = NS * (LO ? 2 : 1) * 1024;     // the hi pieces are the first NS planes of a packed slab
+  constexpr int QD = SLAB / 4 / 1024;
   constexpr int R = CHAIN_RING;
+  // the first PF k-step pieces of the NEXT adjoint phase's a_l are copied into LDS (two 1 KB LDS-DMA copies per GEMM
+  // step from step 0) while this layer's GEMM runs: the phase then starts on data that is already on
+  // chip and its remaining pieces stream into registers behind it.  (All of a_l does not fit: ring + 4 waves x 16 KB
+  // = the CU's 160 KB at width 256.)  Requested in place the loads left an HBM round trip in front of every phase.
+  constexpr int PF = chain_pf_pieces(NTW, K1);
+  constexpr int PF_BYTES = PF * K1 * 1024;           // per wave (<= NTW KB)
+  constexpr int NPF = PF * K1;                       // copies per layer, two per GEMM step from step 0
+  constexpr int PF_STEPS = (NPF + 1) / 2;
+  static_assert(PF_STEPS <= NTW, "prefetch copies fit the GEMM's steps");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4;
   const unsigned lpos = (4u * (lane & 15) + q) * 16u;
   const int nh = P.L - 1;
   const int64_t n_tb = (P.n_tiles + CHAIN_WAVES - 1) / CHAIN_WAVES;
   const int64_t my_tb = (n_tb - blockIdx.x + gridDim.x - 1) / gridDim.x;
+  chain_stagger();
   SlabRing<NTW, SLAB, R, true> ring;               // slab order: layers nh-1 .. 0 (descending), tiles 0 .. NTW-1
-  ring.init(P.WTf, smem, nh, my_tb * nh * NTW, wave, lane);
+  ring.init(P.WTf, P.w_plane, smem, nh, my_tb * nh * NTW, wave, lane);
+  char* pf = smem + R * SLAB + wave * PF_BYTES;    // this wave's prefetch area
   for (int g0 = 0; g0 < R - 1; ++g0) ring.issue();
   int64_t g = 0;
+  CHAIN_DIAG_BEGIN;
   for (int64_t tb = blockIdx.x; tb < n_tb; tb += gridDim.x) {
     int64_t t = tb * CHAIN_WAVES + wave;
     const bool live = t < P.n_tiles;
@@ -273,11 +431,14 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_bwd(const ChainParam
       const __amdgpu_buffer_rsrc_t aop = jet_rsrc(P.A + (int64_t)l * P.jet_stride + tbase, TILE_BYTES);
       const __amdgpu_buffer_rsrc_t zdst = jet_rsrc(P.Z + (int64_t)(l - 1) * P.jet_stride + tbase, TILE_BYTES);
       bf8 zj[K1][NS];
-      // a_{l+1} arrives in k-step pieces, requested AHEAD pieces before their use and no earlier (left alone the
-      // compiler hoists every load of the phase to its top)
+      CHAIN_STAMP(2);
+      // a_{l+1} arrives in k-step pieces: the first PF0 from this wave's LDS prefetch area (l < nh), the rest
+      // requested AHEAD pieces before their use and no earlier (left alone the compiler hoists every load of the
+      // phase to its top and spills)
       auto phase = [&](auto from_mem) {
         constexpr bool MEM = decltype(from_mem)::value;
         constexpr int AHEAD = MEM ? 1 : 2;         // (two streams in the first phase: half the look-ahead each)
+        constexpr int PF0 = MEM ? 0 : PF;
         bf8 av[AHEAD + 1][K1], gv[MEM ? AHEAD + 1 : 1][K1];
         auto request = [&](int s2, int slot) {
 #pragma unroll
@@ -287,18 +448,33 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_bwd(const ChainParam
           }
         };
 #pragma unroll
-        for (int s0 = 0; s0 < AHEAD && s0 < NS; ++s0) request(s0, s0 % (AHEAD + 1));
+        for (int s0 = PF0; s0 < PF0 + AHEAD && s0 < NS; ++s0) request(s0, (s0 - PF0) % (AHEAD + 1));
+        if constexpr (PF0 > 0) {
+          // the prefetch copies were issued at the first PF_STEPS steps of the GEMM above: everything issued at the
+          // later steps (weight copies and jet stores, counted exactly) plus this phase's requests may stay in flight
+          constexpr int YOUNGER = chain_ops_in_steps<K1, NS, QD>(PF_STEPS, NTW) + (NS - PF0 < AHEAD ? NS - PF0 : AHEAD) * K1;
+          if (ring.issued >= ring.total) wait_vm<0>();      // (end of the slab sequence: copies were skipped)
+          else wait_vm<(YOUNGER < 63 ? YOUNGER : 63)>();
+        }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-          if (s + AHEAD < NS) request(s + AHEAD, (s + AHEAD) % (AHEAD + 1));
-          const int cs = s % (AHEAD + 1);
+          bf8 cur[K1];
+          if (s < PF0) {
+#pragma unroll
+            for (int c = 0; c < K1; ++c) cur[c] = *reinterpret_cast<const bf8*>(pf + (s * K1 + c) * 1024 + lpos);
+          } else {
+            if (s + AHEAD < NS) request(s + AHEAD, (s + AHEAD - PF0) % (AHEAD + 1));
+#pragma unroll
+            for (int c = 0; c < K1; ++c) cur[c] = av[(s - PF0) % (AHEAD + 1)][c];
+          }
+          const int cs = (s - PF0) % (AHEAD + 1);
           float o[K1][8];
 #pragma unroll
           for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int j = 4 * h + r;
-              const float a = bf2f(av[cs][0][j]);
+              const float a = bf2f(cur[0][j]);
               const float sv = fmaf(-a, a, 1.f);
               float cross = 0.f;
               float ab[K1];
@@ -309,7 +485,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_bwd(const ChainParam
               }
 #pragma unroll
               for (int c = 1; c < K1; ++c) {
-                cross = fmaf(ab[c], bf2f(av[cs][c][j]), cross);
+                cross = fmaf(ab[c], bf2f(cur[c][j]), cross);
                 o[c][j] = ab[c] * sv;
               }
               o[0][j] = fmaf(-2.f * a, cross, sv * ab[0]);   // tanh'' = -2 a (1 - a^2)
@@ -320,35 +496,65 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_bwd(const ChainParam
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = (__bf16)o[c][j];
             zj[c][s] = v;
-            if (live) st_blk(zdst, lpos, (c * NS + s) * 1024, v);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
       };
       if (l == nh) phase(std::true_type{});
       else phase(std::false_type{});
+      CHAIN_STAMP(3);
       // ---- abar_l = W_l^T zbar_l
       zero_tiles<NTW, K1>(acc);
-#pragma unroll
-      for (int MT = 0; MT < NTW; ++MT) {
-        if (MT < R - 1) ring.template wait_landed<K1 * NS>(g, live);   // (zbar stores of the adjoint phase above)
-        else ring.template wait_landed<0>(g, false);
+      const bool pf_cur = live && l >= 2;          // a_l for the next phase (layer l - 1)
+      const char* pf_src = reinterpret_cast<const char*>(P.A + (int64_t)(l - 1) * P.jet_stride + tbase);
+      static_for<0, NTW>([&](auto mt_) {
+        constexpr int MT = decltype(mt_)::value;
+        CHAIN_STAMP(2);
+        {
+          // zbar_l (= zj, this GEMM's B operand) goes out during this GEMM, two blocks per step, next to one
+          // prefetch copy per step.  Steps before R - 1: slab g was requested before the adjoint phase, whose
+          // load waits have retired it already (vmcnt retires in order): any count is safe there; later steps
+          // count every younger operation exactly.
+          constexpr int E = chain_younger_stores<K1, NS, NTW, R, MT, true, false>();
+          constexpr int EP = chain_younger_prefetch<R, NPF>(MT);
+          static_assert((R - 2) * QD + E + EP <= 63, "vmcnt range");
+          if (live && pf_cur) ring.template wait_landed<E + EP>(g, true);
+          else if (live) ring.template wait_landed<E>(g, true);
+          else ring.template wait_landed<0>(g, false);
+        }
+        CHAIN_STAMP(0);
         __builtin_amdgcn_s_barrier();
+        CHAIN_STAMP(1);
         ring.issue();
+        if constexpr (chain_pf_at<NPF>(MT) > 0) {
+          if (pf_cur) {                            // copy i = block (piece i / K1, quantity i % K1): piece-major
+#pragma unroll
+            for (int i = 2 * MT; i < 2 * MT + chain_pf_at<NPF>(MT); ++i)
+              dma_1k<PINN_CHAIN_JET_LD_AUX>(pf_src + ((i % K1) * NS + i / K1) * 1024, pf + i * 1024, lane);
+          }
+        }
+        if (live) {
+#pragma unroll
+          for (int i = 0; i < chain_stores_at<K1, NS>(MT); ++i) {
+            const int idx = 2 * MT + i;
+            st_blk(zdst, lpos, idx * 1024, zj[idx / NS][idx % NS]);
+          }
+        }
         const char* sl = ring.consume_ptr();
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
           const bf8 ahi = *reinterpret_cast<const bf8*>(sl + s * 1024);
-          const bf8 alo = *reinterpret_cast<const bf8*>(sl + (NS + s) * 1024);
 #pragma unroll
-          for (int c = 0; c < K1; ++c) {
-            acc[c][MT] = mfma32(ahi, zj[c][s], acc[c][MT]);
-            acc[c][MT] = mfma32(alo, zj[c][s], acc[c][MT]);
+          for (int c = 0; c < K1; ++c) acc[c][MT] = mfma32(ahi, zj[c][s], acc[c][MT]);
+          if constexpr (LO) {
+            const bf8 alo = *reinterpret_cast<const bf8*>(sl + (NS + s) * 1024);
+#pragma unroll
+            for (int c = 0; c < K1; ++c) acc[c][MT] = mfma32(alo, zj[c][s], acc[c][MT]);
           }
         }
         ring.consumed();
         ++g;
-      }
+      });
     }
     // abar_1 for the first layer's reverse kernel (bf16: it is consumed together with the bf16 a_1)
     if (live) {
@@ -365,8 +571,10 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_bwd(const ChainParam
           st_blk(g1r, lpos, (c * NS + s) * 1024, v);
         }
     }
+    CHAIN_STAMP(4);
   }
   wait_vm<0>();
+  CHAIN_DIAG_END(P);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -417,7 +625,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_wgrad(const ChainPar
       int c = 2 * ku + cq;
       if (c >= K1) c = K1 - 1;                     // odd K1: the missing quantity is masked at the MFMA operand
       const unsigned short* src = (op ? Al : Zl) + ((t * K1 + c) * NS + s) * 512;
-      dma_1k(src, dst + jj * 1024, lane);
+      dma_1k<PINN_CHAIN_JET_LD_AUX>(src, dst + jj * 1024, lane);
     }
   };
   f4 dw[MTB][NTW];
@@ -433,10 +641,14 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_wgrad(const ChainPar
   // rows = points 8 (qk & 1) + (i16 >> 2) (+4 for the second read), column quad = i16 & 3, at fixed (s, h)
   const int tr_lane = (8 * (qk & 1) + (i16 >> 2)) * 64 + (i16 & 3) * 16;
   const int cq_lane = qk >> 1;                     // which of the unit's two quantities this lane group contracts
+  CHAIN_DIAG_BEGIN;
   for (int64_t u = 0; u < U; ++u) {
+    CHAIN_STAMP(2);
     if (u + RU - 1 > U) wait_vm<0>();              // fewer than RU - 2 younger units exist: drain
     else wait_vm<(RU - 2) * UDMA>();
+    CHAIN_STAMP(0);
     __builtin_amdgcn_s_barrier();
+    CHAIN_STAMP(1);
     issue_unit(u + RU - 1);
     const char* ub = smem + (int)(u % RU) * UNIT;
     const int ku = (int)(u % KU);
@@ -465,6 +677,8 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_wgrad(const ChainPar
     }
   }
   wait_vm<0>();
+  CHAIN_STAMP(2);
+  CHAIN_DIAG_END(P);
   // one flush per wave into the flat torch-layout gradient: dW_l (out, in) row-major, then b_l
   float* dWl = P.dW + P.w_off1 + (int64_t)li * P.w_per;
   float* dbl = dWl + (int64_t)P.W * P.W;

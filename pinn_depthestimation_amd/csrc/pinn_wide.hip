@@ -18,6 +18,11 @@ WGeo wgeo(const Net& n) {
   return g;
 }
 int64_t al256(int64_t v) { return (v + 255) & ~(int64_t)255; }
+// bytes between the 1 KB pieces of a packed weight slab (k_chain_pack): all slabs' piece i, rounded up to 64 KB, + 4 KB
+int64_t chain_plane_bytes(int nh, int NTW) {
+  const int64_t slabs = (int64_t)(nh > 0 ? nh : 1) * NTW * 1024;
+  return ((slabs + 65535) / 65536) * 65536 + 4096;
+}
 
 int cus() { return device_cu_count(); }
 
@@ -62,7 +67,7 @@ WLayout wlayout(const Net& n, const WGeo& g, int64_t N) {
     w.gA = off; off += w.act_stride;
     w.gB = off; off += w.act_stride;
   } else {
-    const int64_t frag = al256((int64_t)(n.L - 1) * g.WP * g.WP * 2 * 2);   // hi + lo bf16 per hidden matrix
+    const int64_t frag = chain_plane_bytes(n.L - 1, g.NTW) * g.NTW;          // hi + lo bf16 per hidden matrix: 2 NS = NTW piece planes
     w.wf = off; off += frag;
     w.wtf = off; off += frag;
     w.jet_stride = al256(w.chunk_tiles * K1 * g.NTW * 256 * 2);
@@ -122,7 +127,11 @@ __global__ void k_wide_reduce_sums(const float* __restrict__ wg_sums, int64_t ro
 //   WTf[li][MT][hl][s][lane][j] = W_l[n(s, qk, j)][16 MT + m]        (reverse: rows = input units)
 // lane = (m = lane & 15, qk = lane >> 4), n(s, qk, j) = 32 s + 16 (j >> 2) + 4 qk + (j & 3): the k index is
 // permuted inside each k-step so that two accumulator tiles are the next B operand as they stand.
-__global__ void k_chain_pack(Net n, int NTW, const float* __restrict__ params, unsigned short* __restrict__ Wf,
+// A slab (li, MT) is 2 NS pieces of 1 KB ([hi | lo][k-step]); piece i of slab n is stored at element
+// i * plane + n * 512: the pieces of one slab are `plane` apart (a multiple of 64 KB plus 4 KB, chain_plane_bytes), so
+// that the 32 CUs of an XCD, which read the same slab at about the same time, spread over the L2's channels
+// instead of queueing on the few that one contiguous 16 KB region maps to.
+__global__ void k_chain_pack(Net n, int NTW, int64_t plane, const float* __restrict__ params, unsigned short* __restrict__ Wf,
                              unsigned short* __restrict__ WTf) {
   const int NS = NTW / 2;
   const int64_t per_layer = (int64_t)NTW * NS * 512;            // (MT, s, lane, j) combinations
@@ -141,8 +150,8 @@ __global__ void k_chain_pack(Net n, int NTW, const float* __restrict__ params, u
   const bool in = row < W && kk < W;
   const float wf = in ? Wl[(int64_t)row * W + kk] : 0.f;
   const float wt = in ? Wl[(int64_t)kk * W + row] : 0.f;
-  const int64_t slab = ((int64_t)li * NTW + MT) * (2 * NS * 512);
-  const int64_t o_hi = slab + (int64_t)s * 512 + lane * 8 + j, o_lo = o_hi + (int64_t)NS * 512;
+  const int64_t slab = ((int64_t)li * NTW + MT) * 512;
+  const int64_t o_hi = (int64_t)s * plane + slab + lane * 8 + j, o_lo = o_hi + (int64_t)NS * plane;
   const __bf16 fh = (__bf16)wf, th = (__bf16)wt;
   Wf[o_hi] = __builtin_bit_cast(unsigned short, fh);
   Wf[o_lo] = __builtin_bit_cast(unsigned short, (__bf16)(wf - (float)fh));
@@ -191,7 +200,7 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
   const int nh = n.L - 1;                                  // hidden (W x W) matrices
   if (chain && nh > 0) {
     const int64_t total = (int64_t)nh * NTW * (NTW / 2) * 512;
-    hipLaunchKernelGGL(k_chain_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, n, NTW, params,
+    hipLaunchKernelGGL(k_chain_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, n, NTW, chain_plane_bytes(nh, NTW) / 2, params,
                        (unsigned short*)(base + w.wf), (unsigned short*)(base + w.wtf));
   }
   auto woff = [&](int l) { return l == 0 ? 0 : g.WP * 16 + (l - 1) * g.WP * g.WP; };
@@ -219,19 +228,36 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
       // bf16 jets), the L - 1 hidden matrices on the three chain kernels (chain_kernel.h) ----
       ChainParams C;
       memset(&C, 0, sizeof(C));
-      C.L = L; C.n_tiles = Lp.n_tiles; C.jet_stride = w.jet_stride / 2;
+      C.L = L; C.n_tiles = Lp.n_tiles; C.jet_stride = w.jet_stride / 2; C.w_plane = chain_plane_bytes(nh, NTW);
       C.Wf = (const unsigned short*)(base + w.wf); C.WTf = (const unsigned short*)(base + w.wtf); C.bias = Bp;
       C.A = (unsigned short*)(base + w.jA); C.Z = (unsigned short*)(base + w.jZ);
       C.GL = (unsigned short*)(base + w.jGL); C.G1 = (unsigned short*)(base + w.jG1);
       C.dW = grad ? rq->grad : nullptr; C.spill = grad ? 1 : 0; C.W = n.W;
       C.w_off1 = n.w_off(1); C.w_per = (int64_t)n.W * n.W + n.W;
+#ifdef PINN_CHAIN_DIAG
+      static unsigned long long* dbuf = nullptr;     // diagnostic build only (never shipped): 3 kernels x 8 phase sums
+      if (!dbuf) { (void)hipMalloc((void**)&dbuf, 24 * sizeof(unsigned long long)); }
+#endif
       auto jetA = [&](int l) { return (float*)(base + w.jA + (int64_t)(l - 1) * w.jet_stride); };   // a_l, l = 1..L
       const int cgrid = (int)((Lp.n_tiles + CHAIN_WAVES - 1) / CHAIN_WAVES < w.grid ? (Lp.n_tiles + CHAIN_WAVES - 1) / CHAIN_WAVES : w.grid);
       Lp.W = Wp; Lp.b = Bp; Lp.out_act = jetA(1);
       rc = launch_wide_fwd<NTW>(0, K1, prec, false, P, Lp, grid, s); if (rc) break;
+#ifdef PINN_CHAIN_DIAG
+      C.diag = dbuf;
+#endif
       if (nh > 0) { rc = launch_chain_fwd<NTW>(K1, C, cgrid, s); if (rc) break; }
       Lp.W = Wp + woff(L); Lp.b = Bp + L * g.WP; Lp.in_act = jetA(L); Lp.out_act = nullptr; Lp.g_out = gout;
       rc = launch_wide_fwd<NTW>(2, K1, prec, grad, P, Lp, grid, s); if (rc) break;
+#ifdef PINN_CHAIN_DIAG
+      if (!grad && nh > 0) {
+        unsigned long long h[8];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost);
+        unsigned long long tot = 0; for (int i = 0; i < 8; ++i) tot += h[i];
+        fprintf(stderr, "CHAIN_DIAG fwd (no spill): wait_dma %.1f%% barrier %.1f%% step %.1f%% act %.1f%% tile-io %.1f%% | total %llu cycles\n",
+                100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, 100.0 * h[4] / tot, tot);
+      }
+#endif
       if (!grad) continue;
       // output layer: dW_L = G . a_L^T ; abar_L = W_L^T G (bf16, chain layout)
       Lp.g_in = gout; Lp.in_act = jetA(L); Lp.in_d = n.in_dim(L); Lp.out_d = n.out_dim(L);
@@ -239,6 +265,9 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
       rc = launch_wide_wgrad<NTW>(2, K1, prec, P, Lp, w.grid, s); if (rc) break;
       Lp.W = WTp + woff(L); Lp.g_out = (float*)C.GL;
       rc = launch_wide_bwd<NTW>(2, K1, prec, P, Lp, grid, s); if (rc) break;
+#ifdef PINN_CHAIN_DIAG
+      C.diag = dbuf + 8;
+#endif
       if (nh > 0) { rc = launch_chain_bwd<NTW>(K1, C, cgrid, s); if (rc) break; }
       // first layer: zbar_0 = adjoint(abar_1, a_1), in place over abar_1; dW_0 = zbar_0 . (x, e_j)^T
       Lp.g_in = (float*)C.G1; Lp.in_act = jetA(1); Lp.g_out = nullptr; Lp.W = nullptr; Lp.z_out = (float*)C.G1;
@@ -249,7 +278,23 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
       if (nh > 0) {
         C.n_slices = w.grid / nh > 0 ? w.grid / nh : 1;
         if ((int64_t)C.n_slices > Lp.n_tiles) C.n_slices = (int)Lp.n_tiles;
+#ifdef PINN_CHAIN_DIAG
+        C.diag = dbuf + 16;
+#endif
         rc = launch_chain_wgrad<NTW>(K1, C, C.n_slices * nh, s); if (rc) break;
+#ifdef PINN_CHAIN_DIAG
+        {
+          unsigned long long h[24];
+          (void)hipStreamSynchronize(s);
+          (void)hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost);
+          const char* nm[3] = {"fwd", "bwd", "wgrad"};
+          for (int k = 0; k < 3; ++k) {
+            unsigned long long tot = 0; for (int i = 0; i < 8; ++i) tot += h[8 * k + i];
+            fprintf(stderr, "CHAIN_DIAG %s: wait_dma %.1f%% barrier %.1f%% step(issue+lds+mfma) %.1f%% act/adjoint %.1f%% tile-io %.1f%% | total %llu cycles\n", nm[k],
+                    100.0 * h[8 * k] / tot, 100.0 * h[8 * k + 1] / tot, 100.0 * h[8 * k + 2] / tot, 100.0 * h[8 * k + 3] / tot, 100.0 * h[8 * k + 4] / tot, tot);
+          }
+        }
+#endif
       }
       continue;
     }
@@ -318,6 +363,7 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
 }  // namespace
 
 bool wide_supports(const Net& n) {
+  if (n.prec == PINN_PREC_BF16 && n.L > 30) return false;   // k_chain_fwd keeps every layer's bias in LDS, behind its ring
   return n.act == PINN_ACT_TANH && n.W > 64 && n.W <= 256 && n.d_in <= 16 && n.d_out <= 16 && n.L >= 1 &&
          (n.K1 == 1 || n.K1 == 3 || n.K1 == 4);
 }
