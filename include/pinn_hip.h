@@ -87,6 +87,14 @@ typedef struct pinn_desc {
   int32_t activation; /* PINN_ACT_* */
   int32_t engine;     /* PINN_ENGINE_* */
   int32_t precision;  /* PINN_PREC_*: operand type of the weight GEMMs */
+  /* nn.Dropout(dropout_rate) after every hidden activation (dnn.py:38) while the module is in training mode
+   * (train.py:186).  0 = identity (eval mode, and every config the reference ships).  The keep mask of unit f of
+   * hidden layer l at point n is a pure function of (dropout_seed, l, f, n) — pinn_dropout_keep below — so a
+   * forward call and the reverse sweep that follows it (same seed) see the same mask without storing it; the caller
+   * draws a new seed per forward pass.  Kept units are scaled by 1 / (1 - p), tangents included.
+   * Runs on the generic engine (AUTO selects it; FUSED / WIDE with dropout_p > 0 are refused). */
+  float dropout_p;
+  uint32_t dropout_seed;
 } pinn_desc;
 
 /* residual ids */
@@ -110,6 +118,10 @@ typedef struct pinn_residual_spec {
 } pinn_residual_spec;
 
 int32_t pinn_version(void);
+
+/* 1 if unit `feature` of hidden layer `layer` (0-based) is kept at point `point` under (seed, p) — the exact mask
+ * the kernels apply (host evaluation of the same function; for tests and for callers that want the mask). */
+int32_t pinn_dropout_keep(uint32_t seed, int32_t layer, int32_t feature, int64_t point, float p);
 const char* pinn_last_error(void);
 
 /* P = sum_l (in_l*out_l + out_l), layers = [d_in] + [width]*n_hidden + [d_out] (train.py:56) */

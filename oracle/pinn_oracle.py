@@ -25,7 +25,7 @@ tests check this oracle against those vectors (tests/test_oracle_golden.py).
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Sequence
+from typing import Optional, Dict, List, Sequence
 
 import torch
 
@@ -86,14 +86,20 @@ def unflatten(flat: torch.Tensor, layers: Sequence[int]) -> List[torch.Tensor]:
     return out
 
 
-def mlp_forward(params: Sequence[torch.Tensor], x: torch.Tensor, init_type: str = "xavier") -> torch.Tensor:
-    """dnn.py:54-55 with dropout p = 0: Linear -> act, last Linear bare."""
+def mlp_forward(params: Sequence[torch.Tensor], x: torch.Tensor, init_type: str = "xavier",
+                masks: Optional[Sequence[torch.Tensor]] = None, p: float = 0.0) -> torch.Tensor:
+    """dnn.py:54-55: Linear -> act -> Dropout(p) per hidden layer, last Linear bare.  masks = None is eval mode /
+    p = 0 (identity).  With masks (one (N, width) 0/1 tensor per hidden layer) this is nn.Dropout in training
+    mode with THAT mask: kept units scaled by 1 / (1 - p) (dnn.py:38) — the mask is an argument so that a test
+    can hand the engine's own mask to this restatement."""
     n_lin = len(params) // 2
     a = x
     for i in range(n_lin):
         a = torch.nn.functional.linear(a, params[2 * i], params[2 * i + 1])
         if i < n_lin - 1:
             a = torch.tanh(a) if init_type == "xavier" else torch.nn.functional.leaky_relu(a, 0.01)
+            if masks is not None:
+                a = a * masks[i].to(a.dtype) / (1.0 - p)
     return a
 
 
@@ -197,11 +203,11 @@ def split_columns(X: torch.Tensor, grad_cols: Sequence[int]) -> List[torch.Tenso
 
 
 def residual_loss(params, X, residual: str, in_roles: Sequence[int], out_roles: Sequence[int],
-                  grad_cols: Sequence[int], init_type="xavier"):
+                  grad_cols: Sequence[int], init_type="xavier", masks=None, p: float = 0.0):
     """train.py:144-154: cat columns -> dnn -> slice (N,1) outputs -> residual fn.
     in_roles / out_roles give the X / Y column of each positional argument."""
     cols = split_columns(X, grad_cols)
-    Y = mlp_forward(params, torch.cat(cols, dim=-1), init_type)
+    Y = mlp_forward(params, torch.cat(cols, dim=-1), init_type, masks, p)
     ins = [cols[i] for i in in_roles]
     outs = [Y[:, o:o + 1] for o in out_roles]
     return RESIDUALS[residual](*ins, *outs)
@@ -221,10 +227,10 @@ def flat_grad(loss: torch.Tensor, params: Sequence[torch.Tensor]) -> torch.Tenso
     return torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(gs, params)])
 
 
-def jet(params, X, grad_cols: Sequence[int], init_type="xavier"):
+def jet(params, X, grad_cols: Sequence[int], init_type="xavier", masks=None, p: float = 0.0):
     """All compute_gradient(out_c, in_j) columns: returns Y (N,d_out), dY (k,N,d_out)."""
     cols = split_columns(X, grad_cols)
-    Y = mlp_forward(params, torch.cat(cols, dim=-1), init_type)
+    Y = mlp_forward(params, torch.cat(cols, dim=-1), init_type, masks, p)
     dY = torch.stack([torch.cat([compute_gradient(Y[:, c:c + 1], cols[j]) for c in range(Y.shape[1])], dim=1)
                       for j in grad_cols])
     return Y.detach(), dY.detach()

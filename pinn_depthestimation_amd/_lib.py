@@ -28,6 +28,7 @@ class PinnDesc(C.Structure):
         ("d_in", C.c_int32), ("d_out", C.c_int32), ("n_hidden", C.c_int32), ("width", C.c_int32),
         ("k", C.c_int32), ("dir_col", C.c_int32 * PINN_MAX_DIRS),
         ("activation", C.c_int32), ("engine", C.c_int32), ("precision", C.c_int32),
+        ("dropout_p", C.c_float), ("dropout_seed", C.c_uint32),
     ]
 
 
@@ -46,6 +47,7 @@ _P = C.c_void_p
 _SIGNATURES = {
     "pinn_version": (C.c_int32, []),
     "pinn_last_error": (C.c_char_p, []),
+    "pinn_dropout_keep": (C.c_int32, [C.c_uint32, C.c_int32, C.c_int32, C.c_int64, C.c_float]),
     "pinn_param_count": (C.c_int32, [C.POINTER(PinnDesc), C.POINTER(C.c_int64)]),
     "pinn_query_workspace": (C.c_int32, [C.POINTER(PinnDesc), C.c_int64, C.POINTER(C.c_int64)]),
     "pinn_forward": (C.c_int32, [C.POINTER(PinnDesc), _P, _P, C.c_int64, _P, _P, C.c_int64, _P]),

@@ -30,12 +30,17 @@ from .engine import ACTIVATION_OF_INIT, Engine, NetDesc, ResidualSpec
 _ENGINES = {}
 
 
-def engine_for(model, grad_cols: Sequence[int], device) -> Engine:
-    key = (tuple(model.layer_sizes), tuple(grad_cols), model.init_type, str(device))
+def engine_for(model, grad_cols: Sequence[int], device, drop=(0.0, 0)) -> Engine:
+    """The engine for this geometry (cached), with the dropout seed of the CURRENT forward pass set on it:
+    drop = (p, seed); every kernel call of one pass, forward and reverse, runs under the pass's own seed."""
+    key = (tuple(model.layer_sizes), tuple(grad_cols), model.init_type, str(device), float(drop[0]))
     if key not in _ENGINES:
-        desc = NetDesc.from_layers(model.layer_sizes, grad_cols, ACTIVATION_OF_INIT[model.init_type])
+        desc = NetDesc.from_layers(model.layer_sizes, grad_cols, ACTIVATION_OF_INIT[model.init_type],
+                                   dropout_p=float(drop[0]))
         _ENGINES[key] = Engine(desc, device)
-    return _ENGINES[key]
+    eng = _ENGINES[key]
+    eng.dropout_seed = int(drop[1])
+    return eng
 
 
 def _split_flat(model, flat_grad: torch.Tensor):
@@ -51,9 +56,9 @@ class _PlainForward(torch.autograd.Function):
     """Y = net(X) with X treated as data; backward = reverse sweep for d/d theta."""
 
     @staticmethod
-    def forward(ctx, model, X, *params):
-        eng = engine_for(model, (), X.device)
-        ctx.model, ctx.eng = model, eng
+    def forward(ctx, model, X, drop, *params):
+        eng = engine_for(model, (), X.device, drop)
+        ctx.model, ctx.drop = model, drop
         ctx.save_for_backward(X)
         return eng.forward(model.flat_params(), X)
 
@@ -63,17 +68,17 @@ class _PlainForward(torch.autograd.Function):
         (X,) = ctx.saved_tensors
         model = ctx.model
         grad = torch.zeros_like(model.flat_params())
-        ctx.eng.jet_backward(model.flat_params(), X, gY.contiguous(), None, grad)
-        return (None, None, *_split_flat(model, grad))
+        engine_for(model, (), X.device, ctx.drop).jet_backward(model.flat_params(), X, gY.contiguous(), None, grad)
+        return (None, None, None, *_split_flat(model, grad))
 
 
 class _JetTangents(torch.autograd.Function):
     """dY[j] = d net(X) / d X[:, grad_cols[j]]  (k, N, d_out), one forward-mode pass."""
 
     @staticmethod
-    def forward(ctx, model, X, grad_cols, *params):
-        eng = engine_for(model, grad_cols, X.device)
-        ctx.model, ctx.eng = model, eng
+    def forward(ctx, model, X, grad_cols, drop, *params):
+        eng = engine_for(model, grad_cols, X.device, drop)
+        ctx.model, ctx.drop, ctx.grad_cols = model, drop, tuple(grad_cols)
         ctx.save_for_backward(X)
         _, dY = eng.forward_jet(model.flat_params(), X)
         return dY
@@ -84,16 +89,17 @@ class _JetTangents(torch.autograd.Function):
         (X,) = ctx.saved_tensors
         model = ctx.model
         grad = torch.zeros_like(model.flat_params())
-        ctx.eng.jet_backward(model.flat_params(), X, None, gdY.contiguous(), grad)
-        return (None, None, None, *_split_flat(model, grad))
+        engine_for(model, ctx.grad_cols, X.device, ctx.drop).jet_backward(model.flat_params(), X, None, gdY.contiguous(), grad)
+        return (None, None, None, None, *_split_flat(model, grad))
 
 
 class JetHandle:
     """What one DNN.forward call knows: the model, the data matrix and which input tensors
     fed which differentiated column."""
 
-    def __init__(self, model, X_data: torch.Tensor, X_graph: torch.Tensor, grad_cols, sources):
+    def __init__(self, model, X_data: torch.Tensor, X_graph: torch.Tensor, grad_cols, sources, drop=(0.0, 0)):
         self.model, self.X, self.X_graph = model, X_data, X_graph
+        self.drop = drop                  # (p, seed) of this forward pass: its tangents / fused residual reuse the mask
         self.grad_cols: Tuple[int, ...] = tuple(grad_cols)
         self.sources = sources            # per grad col: ("leaf", tensor) | ("node", grad_fn) | None
         self._dY: Optional[torch.Tensor] = None
@@ -102,7 +108,7 @@ class JetHandle:
         stale = self._dY is not None and torch.is_grad_enabled() and not self._dY.requires_grad and \
             any(p.requires_grad for p in self.model._ordered_params())
         if self._dY is None or stale:   # never reuse tangents that were built outside the graph
-            self._dY = _JetTangents.apply(self.model, self.X, self.grad_cols, *self.model._ordered_params())
+            self._dY = _JetTangents.apply(self.model, self.X, self.grad_cols, self.drop, *self.model._ordered_params())
         return self._dY
 
     def direction_of(self, var: torch.Tensor) -> Optional[int]:
@@ -242,18 +248,18 @@ def _sniff_sources(model, x: torch.Tensor):
         "model.set_grad_columns([...])")
 
 
-def dnn_forward(model, x: torch.Tensor):
+def dnn_forward(model, x: torch.Tensor, drop=(0.0, 0)):
     if x.dim() != 2 or x.shape[1] != model.layer_sizes[0]:
         raise PinnError(f"input has shape {tuple(x.shape)}, expected (N, {model.layer_sizes[0]})")
     Xd = x.detach().to(torch.float32).contiguous()
     params = model._ordered_params()
-    Y = _PlainForward.apply(model, Xd, *params)
+    Y = _PlainForward.apply(model, Xd, drop, *params)
     if not (x.requires_grad and torch.is_grad_enabled()):
         return Y
     grad_cols, sources = _sniff_sources(model, x)
     if len(grad_cols) == 0:
         return Y
-    handle = JetHandle(model, Xd, x, grad_cols, sources)
+    handle = JetHandle(model, Xd, x, grad_cols, sources, drop)
     Y2 = _AttachInputs.apply(Y, x, handle)
     return JetTensor.wrap(Y2, handle, tuple(range(Y2.shape[1])))
 
@@ -267,7 +273,7 @@ class _FusedResidual(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, handle, spec, *params):
-        eng = engine_for(model, handle.grad_cols, handle.X.device)
+        eng = engine_for(model, handle.grad_cols, handle.X.device, handle.drop)
         flat = model.flat_params()
         N = handle.X.shape[0]
         grad = torch.zeros_like(flat)

@@ -15,6 +15,8 @@ constexpr int FUSED_KERNEL_AUTO = 0, FUSED_KERNEL_TILE = 1, FUSED_KERNEL_COOP = 
 struct Net {
   int d_in, d_out, L /*hidden layers*/, W, k, K1, act, prec;
   int fused_kernel;  // FUSED_KERNEL_*: which fused kernel desc.engine asked for (PINN_ENGINE_FUSED_TILE / _COOP)
+  float drop_p;      // nn.Dropout rate in training mode (dnn.py:38), 0 = off
+  uint32_t drop_seed, drop_thresh;   // keep unit iff dropout_bits(...) >= drop_thresh (= p * 2^32)
   int dir_col[PINN_MAX_DIRS];
   int n_lin;  // L + 1 linear layers
   __host__ __device__ int in_dim(int l) const { return l == 0 ? d_in : W; }
@@ -35,6 +37,23 @@ struct Net {
 };
 
 int make_net(const pinn_desc* d, Net* n);  // validates, returns PINN_OK or error
+
+// Counter-based dropout mask (two rounds of the murmur3 finaliser over (seed, point) then (layer, feature)):
+// 32 uniform bits per (seed, hidden layer, unit, point); the unit is kept iff bits >= p * 2^32.  Stateless, so
+// the reverse sweep re-derives the forward's mask from the same seed (no mask storage, any launch geometry).
+__host__ __device__ inline uint32_t dropout_fmix(uint32_t x) {
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ inline uint32_t dropout_bits(uint32_t seed, uint32_t layer, uint32_t feature, uint64_t point) {
+  uint32_t x = dropout_fmix(seed ^ ((uint32_t)point * 0x9E3779B1u));
+  x ^= (layer * 0x01000193u + feature) * 0x9E3779B1u + (uint32_t)(point >> 32);
+  return dropout_fmix(x);
+}
+__host__ __device__ inline uint32_t dropout_threshold(float p) {
+  const double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+}
 
 // what a loss call asks the engines for
 struct LossReq {

@@ -77,6 +77,9 @@ int make_net(const pinn_desc* d, Net* n) {
   if (d->engine < PINN_ENGINE_AUTO || d->engine > PINN_ENGINE_FUSED_COOP) { set_error("invalid engine %d", d->engine); return PINN_ERR_INVALID; }
   n->fused_kernel = d->engine == PINN_ENGINE_FUSED_TILE ? FUSED_KERNEL_TILE
                   : d->engine == PINN_ENGINE_FUSED_COOP ? FUSED_KERNEL_COOP : FUSED_KERNEL_AUTO;
+  if (!(d->dropout_p >= 0.f && d->dropout_p < 1.f)) { set_error("dropout_p=%g outside [0, 1)", (double)d->dropout_p); return PINN_ERR_INVALID; }
+  n->drop_p = d->dropout_p; n->drop_seed = d->dropout_seed; n->drop_thresh = dropout_threshold(d->dropout_p);
+  if (n->drop_p > 0.f && n->drop_thresh == 0) n->drop_thresh = 1;   // (0 means "off" in the kernels)
   for (int j = 0; j < PINN_MAX_DIRS; ++j) {
     n->dir_col[j] = j < d->k ? d->dir_col[j] : -1;
     if (j < d->k && (d->dir_col[j] < 0 || d->dir_col[j] >= d->d_in)) {
@@ -91,6 +94,14 @@ int make_net(const pinn_desc* d, Net* n) {
 static int pick_engine(const pinn_desc* d, const Net& n, bool want_grad, int* rc) {
   *rc = PINN_OK;
   const int asked = (d->engine == PINN_ENGINE_FUSED_TILE || d->engine == PINN_ENGINE_FUSED_COOP) ? PINN_ENGINE_FUSED : d->engine;
+  if (n.drop_p > 0.f) {     // training-mode dropout lives in the generic engine's kernels
+    if (asked != PINN_ENGINE_AUTO && asked != PINN_ENGINE_GENERIC) {
+      set_error("dropout_p > 0 runs on the generic engine (engine AUTO or GENERIC), not on engine %d", d->engine);
+      *rc = PINN_ERR_UNSUPPORTED;
+    }
+    if (n.prec != PINN_PREC_F32) { set_error("dropout_p > 0 is implemented in fp32 only"); *rc = PINN_ERR_UNSUPPORTED; }
+    return PINN_ENGINE_GENERIC;
+  }
   if (n.prec == PINN_PREC_BF16) {   // bf16 operands exist on the wide engine only
     if ((asked != PINN_ENGINE_AUTO && asked != PINN_ENGINE_WIDE) || !wide_supports(n)) {
       set_error("precision bf16 is implemented on the wide engine (64 < width <= 256, tanh, k in {0,2,3}) only");
@@ -173,6 +184,9 @@ using namespace pinn;
 extern "C" {
 
 int32_t pinn_version(void) { return PINN_ABI_VERSION; }
+int32_t pinn_dropout_keep(uint32_t seed, int32_t layer, int32_t feature, int64_t point, float p) {
+  return dropout_bits(seed, (uint32_t)layer, (uint32_t)feature, (uint64_t)point) >= dropout_threshold(p) ? 1 : 0;
+}
 const char* pinn_last_error(void) { return g_err; }
 
 int32_t pinn_param_count(const pinn_desc* desc, int64_t* count) {

@@ -47,11 +47,20 @@ __global__ void k_seed(const float* __restrict__ X, int d_in, int64_t N, int dir
   }
 }
 
-// mode: 0 = linear output layer, 1 = hidden layer (activation applied)
+// nn.Dropout(p) in training mode (dnn.py:38): what the kernels need of it
+struct Drop {
+  uint32_t thresh;   // 0 = off
+  uint32_t seed;
+  int layer;
+  float scale, keep_p;   // 1 / (1 - p), 1 - p
+};
+
+// mode: 0 = linear output layer, 1 = hidden layer (activation applied, then dropout: a <- m a / (1-p), the
+// tangents likewise — the same mask multiplies value and derivatives, as autograd through nn.Dropout does)
 template <int K1>
 __global__ void k_fwd_layer(const float* __restrict__ Wt, const float* __restrict__ b, int in_dim, int out_dim,
                             const float* __restrict__ a_in, float* __restrict__ a_out, int64_t N, int hidden,
-                            int act) {
+                            int act, Drop dr) {
   int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   for (int o0 = 0; o0 < out_dim; o0 += OB) {
@@ -77,7 +86,13 @@ __global__ void k_fwd_layer(const float* __restrict__ Wt, const float* __restric
     for (int j = 0; j < OB; ++j) {
       if (o0 + j >= out_dim) break;
       float a = acc[0][j], s = 1.f;
-      if (hidden) { a = act_fwd(act, a); s = act_slope(act, a); }
+      if (hidden) {
+        a = act_fwd(act, a); s = act_slope(act, a);
+        if (dr.thresh) {
+          const float m = dropout_bits(dr.seed, dr.layer, o0 + j, n) >= dr.thresh ? dr.scale : 0.f;
+          a *= m; s *= m;
+        }
+      }
       a_out[((int64_t)(o0 + j)) * N + n] = a;
 #pragma unroll
       for (int c = 1; c < K1; ++c) a_out[((int64_t)c * out_dim + o0 + j) * N + n] = s * acc[c][j];
@@ -87,16 +102,24 @@ __global__ void k_fwd_layer(const float* __restrict__ Wt, const float* __restric
 
 // g (in/out): on entry abar' (adjoint of this layer's OUTPUT jet), on exit zbar.
 // g_in: adjoint of the layer's input jet (skipped when need_gin == 0).
+// With dropout the stored jet is masked and scaled: a_out = m c t (t the activation value, c = 1 / (1 - p)), its
+// tangents m c t' zdot.  Then  d a_out / dz = m c t',  d adot_out / dz = -2 t adot_out (tanh)  and
+// d adot_out / dzdot = m c t': the formulas below with  a := t = a_out (1 - p)  and  s := m c t'  (the mask is
+// re-derived from the forward's seed; for a dropped unit a_out = adot_out = 0 and s = 0, so zbar = 0).
 template <int K1>
 __global__ void k_bwd_layer(const float* __restrict__ Wt, int in_dim, int out_dim, float* __restrict__ g,
                             const float* __restrict__ a_out, float* __restrict__ g_in, int64_t N, int hidden,
-                            int act, int need_gin) {
+                            int act, int need_gin, Drop dr) {
   int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   if (hidden) {
     for (int o = 0; o < out_dim; ++o) {
-      const float a = a_out[(int64_t)o * N + n];
-      const float s = act_slope(act, a);
+      float a = a_out[(int64_t)o * N + n];
+      float s;
+      if (dr.thresh) {
+        a *= dr.keep_p;
+        s = dropout_bits(dr.seed, dr.layer, o, n) >= dr.thresh ? dr.scale * act_slope(act, a) : 0.f;
+      } else s = act_slope(act, a);
       float gb = g[(int64_t)o * N + n];
       float cross = 0.f;
 #pragma unroll
@@ -343,9 +366,10 @@ int run_forward(const Net& n, const float* params, const float* X, int64_t N, ch
   hipLaunchKernelGGL(k_seed<K1>, dim3(grid), dim3(TPB), 0, s, X, n.d_in, N, n.dir_col[0], n.dir_col[1],
                      n.dir_col[2], (float*)(ws + lo.act_off[0]));
   for (int l = 0; l <= n.L; ++l) {
+    const Drop dr{n.drop_p > 0.f ? n.drop_thresh : 0u, n.drop_seed, l, 1.f / (1.f - n.drop_p), 1.f - n.drop_p};
     hipLaunchKernelGGL(k_fwd_layer<K1>, dim3(grid), dim3(TPB), 0, s, params + n.w_off(l), params + n.b_off(l),
                        n.in_dim(l), n.out_dim(l), (const float*)(ws + lo.act_off[l]),
-                       (float*)(ws + lo.act_off[l + 1]), N, l < n.L ? 1 : 0, n.act);
+                       (float*)(ws + lo.act_off[l + 1]), N, l < n.L ? 1 : 0, n.act, dr);
   }
   return check_launch("generic forward");
 }
@@ -359,8 +383,9 @@ int run_backward(const Net& n, const float* params, int64_t N, char* ws, const L
   int64_t chunk = 16384;
   for (int l = n.L; l >= 0; --l) {
     const int in_dim = n.in_dim(l), out_dim = n.out_dim(l);
+    const Drop dr{n.drop_p > 0.f ? n.drop_thresh : 0u, n.drop_seed, l, 1.f / (1.f - n.drop_p), 1.f - n.drop_p};
     hipLaunchKernelGGL(k_bwd_layer<K1>, dim3(grid), dim3(TPB), 0, s, params + n.w_off(l), in_dim, out_dim, gcur,
-                       (const float*)(ws + lo.act_off[l + 1]), gnext, N, l < n.L ? 1 : 0, n.act, l > 0 ? 1 : 0);
+                       (const float*)(ws + lo.act_off[l + 1]), gnext, N, l < n.L ? 1 : 0, n.act, l > 0 ? 1 : 0, dr);
     dim3 wg((in_dim + 15) / 16, (out_dim + 15) / 16, (unsigned)((N + chunk - 1) / chunk));
     hipLaunchKernelGGL(k_wgrad<K1>, wg, dim3(256), 0, s, (const float*)gcur, (const float*)(ws + lo.act_off[l]),
                        in_dim, out_dim, N, chunk, grad + n.w_off(l), grad + n.b_off(l));

@@ -5,7 +5,9 @@ initialisation (dnn.py:42-52), nn.Module semantics.  Differences, all deliberate
   * the Linear weights are views into ONE flat fp32 buffer [W0,b0,W1,b1,...] — the layout
     the C-ABI takes — so optimisers updating the Parameters in place update it too;
   * forward() runs on libpinn_hip.so and REQUIRES a GPU tensor: there is no CPU path;
-  * Dropout(p>0) in training mode is not implemented in the engine and raises.
+  * Dropout(p>0) in training mode (dnn.py:38, train.py:186) uses the engine's counter-based mask (one fresh
+    seed per forward call, drawn from torch's CPU generator; include/pinn_hip.h pinn_desc.dropout_p): same
+    distribution as nn.Dropout, not torch's random stream.
 """
 from __future__ import annotations
 
@@ -134,12 +136,11 @@ class DNN(nn.Module):
 
     # ---- forward ----------------------------------------------------------------------------
     def forward(self, x):
-        if self.training and self.dropout_rate > 0.0:
-            raise NotImplementedError(
-                "Dropout(p>0) in training mode is not implemented in the HIP engine "
-                "(every reference config uses dropout_rate 0.0)")
         if not x.is_cuda:
             raise PinnError("DNN.forward needs a GPU tensor: pinn_depthestimation_amd has no CPU path "
                             "(move the model and its inputs to cuda)")
         from .autograd import dnn_forward
-        return dnn_forward(self, x)
+        drop = (0.0, 0)
+        if self.training and self.dropout_rate > 0.0:       # a new mask per forward pass, as nn.Dropout draws one
+            drop = (self.dropout_rate, int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
+        return dnn_forward(self, x, drop)

@@ -40,6 +40,7 @@ class NetDesc:
     activation: int = ACT_TANH
     engine: int = ENGINE_AUTO
     precision: int = 0                   # _lib.PREC_F32 / PREC_BF16 (bf16 MFMA operands, wide engine only)
+    dropout_p: float = 0.0               # nn.Dropout rate applied after every hidden activation (training mode)
 
     @property
     def k(self) -> int:
@@ -57,7 +58,7 @@ class NetDesc:
     def with_(self, **kw) -> "NetDesc":
         d = dict(d_in=self.d_in, d_out=self.d_out, n_hidden=self.n_hidden, width=self.width,
                  grad_cols=self.grad_cols, activation=self.activation, engine=self.engine,
-                 precision=self.precision)
+                 precision=self.precision, dropout_p=self.dropout_p)
         d.update(kw)
         return NetDesc(**d)
 
@@ -70,13 +71,16 @@ class NetDesc:
         for j in range(_lib.PINN_MAX_DIRS):
             d.dir_col[j] = self.grad_cols[j] if j < self.k else -1
         d.activation, d.engine, d.precision = self.activation, self.engine, self.precision
+        d.dropout_p, d.dropout_seed = float(self.dropout_p), 0
         return d
 
     @staticmethod
-    def from_layers(layers: Sequence[int], grad_cols=(), activation=ACT_TANH, engine=ENGINE_AUTO, precision=0) -> "NetDesc":
+    def from_layers(layers: Sequence[int], grad_cols=(), activation=ACT_TANH, engine=ENGINE_AUTO, precision=0,
+                    dropout_p=0.0) -> "NetDesc":
         if len(layers) < 3 or len(set(layers[1:-1])) != 1:
             raise PinnError(f"layers {list(layers)} are not [d_in] + [width]*n + [d_out] (train.py:56)")
-        return NetDesc(layers[0], layers[-1], len(layers) - 2, layers[1], tuple(grad_cols), activation, engine, precision)
+        return NetDesc(layers[0], layers[-1], len(layers) - 2, layers[1], tuple(grad_cols), activation, engine, precision,
+                       dropout_p)
 
 
 @dataclass(frozen=True)
@@ -155,6 +159,8 @@ class Engine:
         self._cdesc: Dict[Tuple[int, int], PinnDesc] = {}
         self._ws: Dict[int, torch.Tensor] = {}
         self._ws_need: Dict[Tuple[int, int], int] = {}
+        self.dropout_seed = 0        # training-mode dropout: the caller sets a fresh seed per forward pass; the
+                                     # reverse sweep of that pass must run under the same one (include/pinn_hip.h)
         cnt = C.c_int64()
         check(self.lib.pinn_param_count(C.byref(desc.c_struct()), C.byref(cnt)), "pinn_param_count")
         self.n_params = cnt.value
@@ -164,7 +170,9 @@ class Engine:
         e = self.desc.engine if engine is None else engine
         if e not in self._cdesc:
             self._cdesc[e] = self.desc.with_(engine=e).c_struct()
-        return self._cdesc[e]
+        d = self._cdesc[e]
+        d.dropout_seed = int(self.dropout_seed) & 0xFFFFFFFF
+        return d
 
     def _chk(self, t: torch.Tensor, name: str, shape=None):
         _chk(t, name, shape)

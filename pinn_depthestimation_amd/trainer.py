@@ -39,9 +39,14 @@ class HipEvaluator:
     """Local-shard loss sums and gradient through libpinn_hip.so."""
 
     def __init__(self, cfg_layers, init_type, grad_cols, spec: ResidualSpec, fid_cols: Sequence[int], device,
-                 engine: int = 0, precision: int = 0):
+                 engine: int = 0, precision: int = 0, dropout_rate: float = 0.0):
         act = ACTIVATION_OF_INIT[init_type]
+        self.dropout_rate = float(dropout_rate)
         self.eng = Engine(NetDesc.from_layers(cfg_layers, grad_cols, act, engine, precision), device)
+        # training-mode dropout (dnn.py:38 with train.py:186): its own engine (generic kernels carry the mask)
+        self.eng_drop = Engine(NetDesc.from_layers(cfg_layers, grad_cols, act, 0, 0, self.dropout_rate), device) \
+            if self.dropout_rate > 0.0 else None
+        self.training = True
         self.spec, self.fid_cols = spec, list(fid_cols)
         self.merge_sets = True      # one launch for both loss terms when the fidelity set is small
         self._cat = None            # [collocation points ; fidelity points], allocated once
@@ -50,6 +55,25 @@ class HipEvaluator:
     MERGE_MAX_FID = 2048   # fidelity points ride through the jet kernel (4x their own work): only when few
 
     def __call__(self, theta, Xf, Tf, fid_scale, Xr, res_scale, grad, fid_sums, res_sums):
+        if self.eng_drop is not None and self.training:
+            # the reference runs the network twice per loss_func call (train.py:133,148): two forward passes, two
+            # masks — one fresh seed per pass, from torch's CPU generator
+            e = self.eng_drop
+            if Xf is not None and Xf.shape[0] > 0:
+                e.dropout_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+                if Xf is Xr:
+                    e.residual_mse_loss_grad(self.spec, res_scale, Tf, self.fid_cols, fid_scale, theta, Xr, grad,
+                                             term_sums=res_sums, col_sums=fid_sums)
+                    return
+                e.mse_loss_grad(theta, Xf, Tf, self.fid_cols, fid_scale, grad, sums=fid_sums)
+            else:
+                fid_sums.zero_()
+            if Xr is not None and Xr.shape[0] > 0:
+                e.dropout_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+                e.residual_loss_grad(self.spec, res_scale, theta, Xr, grad, sums=res_sums)
+            else:
+                res_sums.zero_()
+            return
         if (self.merge_sets and Xf is not None and Xr is not None and Xf is not Xr
                 and 0 < Xf.shape[0] <= self.MERGE_MAX_FID and Xr.shape[0] > 0):
             # train.py:131-157 in ONE launch: collocation points first, fidelity points after them
@@ -146,7 +170,7 @@ class PINN:
         self.grad = self.buf[:P]
         self._fid_sums, self._res_sums = self.buf[P:P + nf], self.buf[P + nf:]
         self.evaluator = evaluator or HipEvaluator(cfg.layers, cfg.init_type, cfg.grad_cols, self.spec,
-                                                   self.fid_cols, dev, engine, precision)
+                                                   self.fid_cols, dev, engine, precision, cfg.dropout_rate)
 
         # optional resampled collocation mini-batch (the reference is full-batch only):
         # each closure draws `residual_batch` of this rank's points with a device-side generator
@@ -196,6 +220,8 @@ class PINN:
         if self.mat_dump_iter is not None and self.iter == self.mat_dump_iter:
             self.dump_predictions(self.mat_dump_path)                      # train_newmethod.py:141-153
         self.buf.zero_()
+        if hasattr(self.evaluator, "training"):
+            self.evaluator.training = self.dnn.training          # dropout follows the module's mode (train.py:186)
         Xr = self.Xr
         if self.residual_batch is not None:
             idx = torch.randint(0, self.Xr.shape[0], (self.residual_batch,), device=self.device, generator=self._gen)

@@ -101,8 +101,9 @@ def g7_end_model():
     return m, z["X"]
 
 
-def g8b():
+def g8b(threads=8, save=True):
     from scipy.optimize import minimize
+    torch.set_num_threads(threads)
     m, X = g7_end_model()
     c = MG.cols_of(X[:2000], (0, 1, 2))
     params = list(m.parameters())
@@ -134,36 +135,51 @@ def g8b():
     res = minimize(fun, x0, jac=True, method="L-BFGS-B", callback=cb2,
                    options={"maxiter": 50, "maxfun": 50000, "maxcor": 50, "maxls": 50,
                             "ftol": 1.0 * np.finfo(float).eps})
-    print("g8b: nit", res.nit, "nfev", res.nfev, "f0", evals[0], "f_end", res.fun, res.message)
+    print("g8b: threads", threads, "nit", res.nit, "nfev", res.nfev, "f0", evals[0], "f_end", res.fun, res.message)
+    torch.set_num_threads(8)
+    if not save:
+        return np.array(evals, np.float64), float(res.fun)
     MG.save("g8b_scipy_lbfgsb_ns_8x64.npz", evals=np.array(evals, np.float64), accepted=np.array(acc, np.float64),
             nit=np.int64(res.nit), nfev=np.int64(res.nfev), fun=np.float64(res.fun),
             x_end=res.x.astype(np.float32))
 
 
 def g8s():
-    """G8 again at 1 thread: |trajectory(8 threads) - trajectory(1 thread)| is the reference's own spread."""
+    """G8 (torch.optim.LBFGS) and G8b (SciPy L-BFGS-B) again at 1, 2 and 4 threads: how far the REFERENCE's own
+    trajectories move when only the summation order of its fp32 kernels changes.  Stored: the per-evaluation maximum
+    over the three re-runs of |loss(k threads) - loss(8 threads)| / loss(8 threads), and the end-loss spread."""
     z8 = np.load(os.path.join(OUT, "g8_lbfgs_ns_8x64.npz"))
-    torch.set_num_threads(1)
-    m, X = g7_end_model()
-    c2 = MG.cols_of(X[:2000], (0, 1, 2))
-    lb = torch.optim.LBFGS(m.parameters(), lr=1, max_iter=50, max_eval=None, history_size=100,
-                           tolerance_grad=1e-5, tolerance_change=1e-7, line_search_fn="strong_wolfe")
-    losses = []
+    zb = np.load(os.path.join(OUT, "g8b_scipy_lbfgsb_ns_8x64.npz"))
+    sp_t, sp_s, end_s = None, None, []
+    for th in (1, 2, 4):
+        torch.set_num_threads(th)
+        m, X = g7_end_model()
+        c2 = MG.cols_of(X[:2000], (0, 1, 2))
+        lb = torch.optim.LBFGS(m.parameters(), lr=1, max_iter=50, max_eval=None, history_size=100,
+                               tolerance_grad=1e-5, tolerance_change=1e-7, line_search_fn="strong_wolfe")
+        losses = []
 
-    def closure():
-        lb.zero_grad()
-        loss, _ = ns_loss(m, c2)
-        loss.backward()
-        losses.append(loss.item())
-        return loss
+        def closure():
+            lb.zero_grad()
+            loss, _ = ns_loss(m, c2)
+            loss.backward()
+            losses.append(loss.item())
+            return loss
 
-    lb.step(closure)
-    torch.set_num_threads(8)
-    a, b = np.array(losses), z8["losses"]
-    n = min(len(a), len(b))
-    spread = np.abs(a[:n] - b[:n]) / np.abs(b[:n])
-    print("g8s: evals", len(a), len(b), "spread first 10", spread[:10].max(), "first 20", spread[:20].max(), "all", spread.max())
-    MG.save("g8s_lbfgs_thread_spread.npz", losses_1thread=a, spread=spread)
+        lb.step(closure)
+        torch.set_num_threads(8)
+        a, b = np.array(losses), z8["losses"]
+        n = min(len(a), len(b))
+        s1 = np.full(len(b), np.nan); s1[:n] = np.abs(a[:n] - b[:n]) / np.abs(b[:n])
+        sp_t = s1 if sp_t is None else np.fmax(sp_t, s1)
+        ev, fend = g8b(th, save=False)
+        n = min(len(ev), len(zb["evals"]))
+        s2 = np.full(len(zb["evals"]), np.nan); s2[:n] = np.abs(ev[:n] - zb["evals"][:n]) / zb["evals"][:n]
+        sp_s = s2 if sp_s is None else np.fmax(sp_s, s2)
+        end_s.append(abs(fend - float(zb["fun"])) / float(zb["fun"]))
+        print("g8s threads", th, "torch first10 %.2e first20 %.2e all %.2e | scipy first12 %.2e all %.2e end %.2e"
+              % (np.nanmax(s1[:10]), np.nanmax(s1[:20]), np.nanmax(s1), np.nanmax(s2[:12]), np.nanmax(s2), end_s[-1]))
+    MG.save("g8s_lbfgs_thread_spread.npz", spread=sp_t, scipy_spread=sp_s, scipy_end_spread=np.float64(max(end_s)))
 
 
 def g9x():

@@ -167,15 +167,28 @@ def test_flat_parameter_storage_tracks_optimizers_and_moves():
     assert type(m2).__name__ == "DNN" and torch.equal(m2.flat_params(), m.flat_params())
 
 
-def test_forward_refuses_cpu_and_dropout():
+def test_forward_refuses_cpu_tensors_in_both_modes():
     import dnn
     m = dnn.DNN([2, 4, 4, 1], 0.5, "xavier")
-    m.train()
-    with pytest.raises(NotImplementedError, match="Dropout"):
-        m(torch.zeros(3, 2))
-    m.eval()
-    with pytest.raises(PinnError, match="no CPU path"):
-        m(torch.zeros(3, 2))
+    for mode in (m.train, m.eval):
+        mode()
+        with pytest.raises(PinnError, match="no CPU path"):
+            m(torch.zeros(3, 2))
+
+
+def test_dropout_refused_on_the_mfma_engines_and_bad_rates_rejected():
+    """pinn_desc.dropout_p > 0 runs on the generic engine: AUTO routes there, explicit FUSED / WIDE are refused at
+    the C-ABI (no GPU needed: pinn_query_workspace validates and picks the engine)."""
+    lib = _lib.load()
+    need = C.c_int64()
+    ok = NetDesc(3, 4, 8, 64, (0, 1, 2), dropout_p=0.2)
+    assert lib.pinn_query_workspace(C.byref(ok.c_struct()), 1000, C.byref(need)) == 0 and need.value > 0
+    for eng in (2, 3, 4):
+        bad = NetDesc(3, 4, 8, 64 if eng != 3 else 128, (0, 1, 2), engine=eng, dropout_p=0.2)
+        assert lib.pinn_query_workspace(C.byref(bad.c_struct()), 1000, C.byref(need)) == -2
+        assert b"generic engine" in lib.pinn_last_error()
+    for p in (-0.1, 1.0):
+        assert lib.pinn_query_workspace(C.byref(NetDesc(3, 4, 8, 64, (0, 1, 2), dropout_p=p).c_struct()), 10, C.byref(need)) == -1
 
 
 # ---- graph sniffing ------------------------------------------------------------------------------------
@@ -409,3 +422,45 @@ def test_checkpoint_written_by_the_reference_class_loads_into_this_dnn(tmp_path)
     m2 = DNN([2] + [10] * 10 + [6], 0.0, "xavier")
     m2.load_state_dict(sd)
     assert torch.equal(m2.flat_params(), flat)
+
+
+def test_dropout_mask_replica_equals_the_librarys_function():
+    """tests/dropout_util.py (numpy) against pinn_dropout_keep (the same source the kernels compile): every test
+    that hands 'the engine's mask' to the oracle relies on this equality."""
+    from tests.dropout_util import keep_masks
+    lib = _lib.load()
+    rng = np.random.RandomState(0)
+    for seed, p in ((1, 0.1), (123456789, 0.5), (2 ** 31 - 2, 0.9)):
+        masks = keep_masks(seed, p, 3, 20, 50)
+        for _ in range(300):
+            l, f, n = rng.randint(3), rng.randint(20), rng.randint(50)
+            assert lib.pinn_dropout_keep(seed, l, f, n, p) == int(masks[l][n, f]), (seed, p, l, f, n)
+    big = (1 << 33) + 12345                                          # point indices beyond 2^32 (the high word is hashed in)
+    from tests.dropout_util import dropout_bits
+    assert lib.pinn_dropout_keep(7, 2, 5, big, 0.5) == int(dropout_bits(7, 2, 5, big) >= np.uint64(1 << 31))
+    m = keep_masks(99, 0.3, 4, 64, 4000)
+    assert abs(np.mean([x.mean() for x in m]) - 0.7) < 0.01                               # keep rate 1 - p
+    assert abs(np.corrcoef(m[0][:, 0], m[0][:, 1])[0, 1]) < 0.05                          # units decorrelated
+    assert abs(np.corrcoef(m[0][:-1, 3], m[0][1:, 3])[0, 1]) < 0.05                       # points decorrelated
+    assert abs(np.corrcoef(m[0].ravel(), m[1].ravel())[0, 1]) < 0.02                      # layers decorrelated
+
+
+def test_oracle_dropout_is_nn_dropout_with_an_explicit_mask():
+    """oracle.mlp_forward(masks, p) restates Linear -> Tanh -> Dropout(p) (dnn.py:36-38) for a GIVEN mask:
+    checked against torch's own nn.Dropout by capturing the mask it drew (output / input of the module)."""
+    from oracle import pinn_oracle as O
+    torch.manual_seed(0)
+    p = 0.3
+    lin = [torch.nn.Linear(3, 16), torch.nn.Linear(16, 16), torch.nn.Linear(16, 2)]
+    drops = [torch.nn.Dropout(p), torch.nn.Dropout(p)]
+    x = torch.rand(40, 3)
+    masks, a = [], x
+    for i in range(2):
+        t = torch.tanh(lin[i](a))
+        a = drops[i](t)                                   # training mode: zeroes with prob p, scales by 1/(1-p)
+        masks.append((a != 0).float())
+    y_ref = lin[2](a)
+    params = [q.detach() for l in lin for q in (l.weight, l.bias)]
+    y = O.mlp_forward(params, x, "xavier", masks, p)
+    assert torch.allclose(y, y_ref, atol=1e-6)
+    assert torch.allclose(O.mlp_forward(params, x), lin[2](torch.tanh(lin[1](torch.tanh(lin[0](x))))), atol=1e-6)

@@ -254,3 +254,90 @@ def test_lbfgs_device_recursion_matches_torch_formulation():
         H = float(y.dot(s) / y.dot(y))
         da, db = a.direction(grad, H), b.direction(grad, H)
         assert float((da - db).norm() / da.norm()) < 2e-5, it
+
+
+@pytest.mark.parametrize("p", [0.1, 0.5])
+@pytest.mark.parametrize("shape", [("ns", 3, 4, 3, 24, (0, 1, 2), "Navier_Stokes", ("t", "x", "y"), ("h", "z", "u", "v")),
+                                   ("pe", 2, 6, 8, 64, (0, 1), "physics_equation", ("x", "y"), ("h", "U", "V", "eta_mean", "Hrms", "k"))])
+def test_dropout_training_mode_matches_oracle_with_the_engines_mask(shape, p):
+    """nn.Dropout(p > 0) after every activation in training mode (dnn.py:38, train.py:186).  The
+    engine's mask is a pure function of (seed, layer, unit, point): the same mask (tests/dropout_util.py) handed to
+    the oracle must give the same outputs, input derivatives, loss and parameter gradient."""
+    from tests.dropout_util import keep_masks
+    from tests.test_engine_gpu import rel_l2
+    _, d_in, d_out, L, W, gc, res, inn, outn = shape
+    N, seed = 333, 20241004
+    g = torch.Generator().manual_seed(17)
+    params = O.init_params(O.layer_sizes(d_in, L, W, d_out), "xavier", g)
+    if res == "physics_equation":
+        params[-1][0] = 0.75; params[-1][3] = 0.0
+    X = torch.rand(N, d_in, generator=g) * 2 - 1
+    masks = [torch.from_numpy(m).double() for m in keep_masks(seed, p, L, W, N)]
+    from pinn_depthestimation_amd import Engine, NetDesc, ResidualSpec
+    from pinn_depthestimation_amd.engine import RESIDUAL_ROLES
+    desc = NetDesc(d_in, d_out, L, W, gc, dropout_p=p)
+    eng = Engine(desc)
+    eng.dropout_seed = seed
+    flat, Xd = O.flatten(params).cuda(), X.cuda().contiguous()
+    p64 = [q.double().requires_grad_(True) for q in params]
+    Yo, dYo = O.jet(p64, X.double(), gc, masks=masks, p=p)
+    Y, dY = eng.forward_jet(flat, Xd)
+    assert (Y.cpu().double() - Yo).abs().max() < 5e-6
+    assert (dY.cpu().double() - dYo).abs().max() < 5e-6 * max(1.0, float(dYo.abs().max()))
+    _, out_roles, dir_roles = RESIDUAL_ROLES[res]
+    lo = O.residual_loss(p64, X.double(), res, [inn.index(r) for r in dir_roles], [outn.index(r) for r in out_roles], gc,
+                         masks=masks, p=p)
+    go = O.flat_grad(lo, p64)
+    spec = ResidualSpec.from_names(res, inn, gc, outn)
+    scale = torch.full((spec.n_terms,), 1.0 / N, device="cuda")
+    grad = torch.zeros(desc.n_params, device="cuda")
+    sums = eng.residual_loss_grad(spec, scale, flat, Xd, grad)
+    loss = float((sums.double() * scale.double()).sum())
+    # tolerance: the engine's usual fp32 bars, or 4x the oracle's OWN fp32-vs-fp64 disagreement on this masked
+    # network (physics_equation's 1/(rho (eta_mean + h)) is ill-conditioned, more so with half the units dropped)
+    p32 = [q.clone().requires_grad_(True) for q in params]
+    l32 = O.residual_loss(p32, X, res, [inn.index(r) for r in dir_roles], [outn.index(r) for r in out_roles], gc,
+                          masks=[m.float() for m in masks], p=p)
+    noise_l = abs(float(l32) - float(lo)) / float(lo)
+    noise_g = rel_l2(O.flat_grad(l32, p32), go)
+    el, eg = abs(loss - float(lo)) / float(lo), rel_l2(grad.cpu(), go)
+    print(f"dropout p={p} {res}: loss err {el:.2e} (oracle fp32 {noise_l:.1e}), grad err {eg:.2e} (oracle fp32 {noise_g:.1e})")
+    assert el < max(5e-6, 4 * noise_l)
+    assert eg < max(3e-5, 4 * noise_g)
+    # another seed is another mask; p = 0 / eval is the plain network
+    eng.dropout_seed = seed + 1
+    assert (eng.forward(flat, Xd) - Y).abs().max() > 1e-3
+    y_plain = Engine(NetDesc(d_in, d_out, L, W, gc)).forward(flat, Xd)
+    assert (y_plain.cpu().double() - O.mlp_forward([q.double() for q in params], X.double())).abs().max() < 5e-6
+
+
+def test_dropout_module_semantics_and_training_run():
+    """dnn.DNN(p > 0): eval() is the identity network, train() draws a new mask per forward (inverted-dropout
+    scaling keeps the mean), and the pinn harness trains with it (fused engines refuse dropout loudly)."""
+    import dnn
+    from pinn_depthestimation_amd import Engine, NetDesc, PinnError
+    from pinn_depthestimation_amd.trainer import pinn
+    torch.manual_seed(5)
+    m = dnn.DNN([3, 64, 64, 4], 0.25, "xavier").cuda()
+    x = torch.rand(4096, 3, device="cuda")
+    m.eval()
+    y0 = m(x)
+    assert torch.equal(m(x), y0)
+    m.train()
+    y1, y2 = m(x), m(x)
+    assert (y1 - y2).abs().max() > 1e-3                                  # two forward passes, two masks
+    mean_train = torch.stack([m(x) for _ in range(64)]).mean(0)
+    assert (mean_train - y0).abs().mean() < 0.1 * y0.abs().mean() + 0.05  # inverted dropout: roughly unbiased
+    with pytest.raises(PinnError, match="generic engine"):
+        Engine(NetDesc(3, 4, 2, 64, (0, 1, 2), engine=2, dropout_p=0.25)).forward(m.flat_params(), x)
+    cfg = ns_config(30)
+    cfg["layers"]["dropout_rate"] = 0.1
+    cfg["layers"]["init_type"] = "xavier"
+    z7 = load("g7_adam_ns_8x64.npz")
+    tr = pinn(None, None, z7["X"][:2000], cfg, log_every=1, checkpoint_every=0)
+    tr.train()
+    losses = np.array([h[3] for h in tr.history])
+    assert np.all(np.isfinite(losses)) and losses[-5:].mean() < losses[:5].mean()
+    tr.dnn.eval()
+    a = float(tr.loss_func()); b = float(tr.loss_func())
+    assert a == pytest.approx(b, rel=1e-5)                               # eval mode: deterministic, no mask
