@@ -45,7 +45,7 @@ constexpr int CHAIN_WAVES = 4;
 constexpr int CHAIN_THREADS = CHAIN_WAVES * 64;
 constexpr int CHAIN_RING = 6;              // weight slabs in the LDS ring of the reverse chain (next to its prefetch areas)
 #ifndef PINN_CHAIN_RING_FWD
-#define PINN_CHAIN_RING_FWD 8
+#define PINN_CHAIN_RING_FWD 6
 #endif
 constexpr int CHAIN_RING_FWD = PINN_CHAIN_RING_FWD;   // ... of the forward chain
 // Weight precision of the REVERSE chain.  Measured on the reference's 12 x 256 golden (G10): rounding the weights to

@@ -363,7 +363,7 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
 }  // namespace
 
 bool wide_supports(const Net& n) {
-  if (n.prec == PINN_PREC_BF16 && n.L > 30) return false;   // k_chain_fwd keeps every layer's bias in LDS, behind its ring
+  if (n.prec == PINN_PREC_BF16 && n.L > 49) return false;   // k_chain_fwd keeps every layer's bias in LDS, behind its ring
   return n.act == PINN_ACT_TANH && n.W > 64 && n.W <= 256 && n.d_in <= 16 && n.d_out <= 16 && n.L >= 1 &&
          (n.K1 == 1 || n.K1 == 3 || n.K1 == 4);
 }

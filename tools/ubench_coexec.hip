@@ -207,6 +207,89 @@ static void run(const char* name, int wps, float* out, double ghz) {
          name, wps, NM, NV, NACC, cyc, NM * 32, NV * 4);
 }
 
+// ---- round 2: ONE wave, K hand-pinned fillers behind every MFMA, for the MFMA forms whose gap is longer than the
+// fp32 16x16x4's (guide rows 'vector-instruction ISSUE cost' / 'single-issue instructions HIDDEN').
+//   KIND 0: v_mfma_f32_16x16x4_f32   (32-cycle issue, the form k_fused uses)
+//   KIND 1: v_mfma_f32_32x32x2_f32   (64-cycle issue, same flop rate)
+//   KIND 2: v_mfma_f32_16x16x32_bf16 (16-cycle issue, the form the chain kernels use)
+//   KIND 3: v_mfma_f32_32x32x16_bf16 (32-cycle issue)
+// TRANS: every filler is a v_exp_f32 (8-cycle issue) instead of a v_fma_f32 (4).
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+template <int KIND> struct Acc { typedef f4 type; };
+template <> struct Acc<1> { typedef f16v type; };
+template <> struct Acc<3> { typedef f16v type; };
+template <int KIND>
+__device__ __forceinline__ typename Acc<KIND>::type mf(float a, float b, bf8v av, bf8v bv, typename Acc<KIND>::type c) {
+  if constexpr (KIND == 0) return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  else if constexpr (KIND == 1) return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  else if constexpr (KIND == 2) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c, 0, 0, 0);
+}
+template <int KIND, int NM, int K, bool TRANS>
+__global__ __launch_bounds__(256) void ub_inter2(float* out, int iters, float x) {
+  constexpr int NACC = 4;
+  typename Acc<KIND>::type acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i)
+#pragma unroll
+    for (int j = 0; j < (int)(sizeof(acc[0]) / 4); ++j) acc[i][j] = 0.f;
+  float a = threadIdx.x * 1e-3f, b = x;
+  bf8v av, bv;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { av[j] = (__bf16)(a + j); bv[j] = (__bf16)(b - j); }
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = a + i;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      acc[i % NACC] = mf<KIND>(a, b, av, bv, acc[i % NACC]);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        float& t = v[(i * K + k) % 8];
+        t = TRANS ? __builtin_amdgcn_exp2f(t) : fmaf(t, b, a);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (K > 0) __builtin_amdgcn_sched_group_barrier(TRANS ? 0x400 : 0x002, K, 0);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i)
+#pragma unroll
+    for (int j = 0; j < (int)(sizeof(acc[0]) / 4); ++j) s += acc[i][j];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int KIND, int K, bool TRANS>
+static double time_inter2(float* out, double ghz) {
+  constexpr int NM = 64;
+  const int iters = 2000, grid = 256;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  hipLaunchKernelGGL((ub_inter2<KIND, NM, K, TRANS>), dim3(grid), dim3(256), 0, 0, out, 10, 1.0001f);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0);
+  hipLaunchKernelGGL((ub_inter2<KIND, NM, K, TRANS>), dim3(grid), dim3(256), 0, 0, out, iters, 1.0001f);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  return ms * 1e-3 * ghz * 1e9 / iters / NM;
+}
+template <int KIND, bool TRANS>
+static void table_inter2(const char* name, int gap, float* out, double ghz) {
+  printf("%-28s gap %2d | %s fillers per MFMA: K=0 %6.1f  K=1 %6.1f  K=2 %6.1f  K=3 %6.1f  K=4 %6.1f  K=5 %6.1f  K=6 %6.1f  K=8 %6.1f  cycles per MFMA+fillers\n",
+         name, gap, TRANS ? "v_exp_f32" : "v_fma_f32", time_inter2<KIND, 0, TRANS>(out, ghz), time_inter2<KIND, 1, TRANS>(out, ghz),
+         time_inter2<KIND, 2, TRANS>(out, ghz), time_inter2<KIND, 3, TRANS>(out, ghz), time_inter2<KIND, 4, TRANS>(out, ghz),
+         time_inter2<KIND, 5, TRANS>(out, ghz), time_inter2<KIND, 6, TRANS>(out, ghz), time_inter2<KIND, 8, TRANS>(out, ghz));
+}
+
 int main() {
   float* out;
   (void)hipMalloc(&out, 256 * 512 * sizeof(float));
@@ -233,6 +316,14 @@ int main() {
   run_inter<128, 4, 4>(out, ghz);
   run_inter<128, 6, 4>(out, ghz);
   run_inter<128, 8, 4>(out, ghz);
+  printf("---- one wave per SIMD, K fillers pinned behind every MFMA (host-timed at the nominal clock; compare rows, the chip clocks down under load) ----\n");
+  table_inter2<0, false>("v_mfma_f32_16x16x4_f32", 32, out, ghz);
+  table_inter2<1, false>("v_mfma_f32_32x32x2_f32", 64, out, ghz);
+  table_inter2<2, false>("v_mfma_f32_16x16x32_bf16", 16, out, ghz);
+  table_inter2<3, false>("v_mfma_f32_32x32x16_bf16", 32, out, ghz);
+  table_inter2<0, true>("v_mfma_f32_16x16x4_f32", 32, out, ghz);
+  table_inter2<1, true>("v_mfma_f32_32x32x2_f32", 64, out, ghz);
+  table_inter2<3, true>("v_mfma_f32_32x32x16_bf16", 32, out, ghz);
   long long* cyc;
   (void)hipMalloc(&cyc, 8 * sizeof(long long));
   run_roles<128, 512>(out, cyc, 1);
