@@ -209,6 +209,21 @@ int32_t pinn_lbfgs_direction(const float* S, const float* Y, const double* M, in
                              int32_t head, int32_t k, const float* g, double H, float* d,
                              double* tmp, float* coef, float* q, void* stream);
 
+/* ---- staging of the collocation points on the device (train.py:246-277, operations.py:4-30) --------------------
+ * The reference loads each input variable as a (ny, nx) float64 grid (scipy.io.loadmat), subsamples it with
+ * [::interval_x, ::interval_y] (train.py:260), maps it onto [-1, 1] with the variable's (min, max) (operations.py:4-8;
+ * a degenerate range gives zeros), flattens it COLUMN-major (train.py:265-267), stacks the variables as columns and
+ * drops every row that holds a NaN (train.py:276-277).  These two calls do the same on grids already resident on the
+ * device, in float64 and in NumPy's order of operations, casting to fp32 last (train.py:88): bit-identical to the
+ * host path.  pinn_nanminmax_f64 is np.nanmin / np.nanmax (operations.py:26-27; {NaN, NaN} for an all-NaN array).
+ * grids: HOST array of d_in DEVICE pointers (ny * nx doubles each, row-major); minmax: device (d_in, 2) doubles;
+ * X_out: device, room for ceil(ny/ix) * ceil(nx/iy) rows of d_in floats; n_rows_out: device, rows actually written. */
+int32_t pinn_nanminmax_f64(const double* data, int64_t n, double* out2, void* ws, int64_t ws_bytes, void* stream);
+int64_t pinn_stage_workspace_bytes(int64_t ny, int64_t nx, int32_t interval_x, int32_t interval_y);
+int32_t pinn_stage_grid_columns(const double* const* grids, int32_t d_in, int64_t ny, int64_t nx, int32_t interval_x,
+                                int32_t interval_y, const double* minmax, float* X_out, int64_t* n_rows_out,
+                                void* ws, int64_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,10 @@ _SIGNATURES = {
     "pinn_lbfgs_push": (C.c_int32, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P]),
     "pinn_lbfgs_direction": (C.c_int32, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, C.c_double, _P,
                                          _P, _P, _P, _P]),
+    "pinn_nanminmax_f64": (C.c_int32, [_P, C.c_int64, _P, _P, C.c_int64, _P]),
+    "pinn_stage_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "pinn_stage_grid_columns": (C.c_int32, [C.POINTER(_P), C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, _P,
+                                            C.c_int64, _P]),
     "pinn_adam_step": (C.c_int32, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double,
                                    C.c_double, _P]),
 }

@@ -58,7 +58,7 @@ NEWMETHOD = {
 # ---- C-ABI -------------------------------------------------------------------------------------
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "pinn_hip.h")).read()
-    declared = set(re.findall(r"\b(pinn_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(pinn_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
     lib = _lib.load()
     for name in declared:
