@@ -85,7 +85,10 @@ struct ChainParams {
 #define CHAIN_STAMP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); dg[i] += t_ - tprev; tprev = t_; } while (0)
 #define CHAIN_DIAG_BEGIN unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter()
 #define CHAIN_DIAG_END(P) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (P).diag) for (int i_ = 0; i_ < 8; ++i_) (P).diag[i_] = dg[i_]; } while (0)
+// 8-wave kernels: wave 0 (an early wave) into the kernel's slots, wave 4 (its late SIMD partner) into slots 24..31
+#define CHAIN_DIAG_END8(P) do { if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && (P).diag) for (int i_ = 0; i_ < 8; ++i_) (P).diag[(threadIdx.x ? 24 : 0) + i_] = dg[i_]; } while (0)
 #else
+#define CHAIN_DIAG_END8(P) do { } while (0)
 #define CHAIN_STAMP(i) do { } while (0)
 #define CHAIN_DIAG_BEGIN do { } while (0)
 #define CHAIN_DIAG_END(P) do { } while (0)
@@ -167,7 +170,7 @@ __device__ __forceinline__ void chain_stagger() {
 
 // The weight ring of the two chain kernels.  Slabs are consumed in a fixed order (tile batch, layer, output tile);
 // `next` walks that order one slab ahead of the R - 1 in flight.  Everything is wave-uniform.
-template <int NTW, int SLAB, int R, bool DESCENDING>
+template <int NTW, int SLAB, int R, bool DESCENDING, int NW = CHAIN_WAVES>
 struct SlabRing {
   const char* base; char* lds; int nh, wave, lane; int64_t plane;
   int64_t issued, total;      // slabs issued so far / slabs this workgroup consumes
@@ -179,10 +182,11 @@ struct SlabRing {
   }
   __device__ __forceinline__ void issue() {
     if (issued >= total) return;
-    constexpr int QDMA = SLAB / 4 / 1024;
+    constexpr int QDMA = SLAB / NW / 1024;
+    static_assert(QDMA * NW * 1024 == SLAB, "every wave copies whole 1 KB pieces of a slab");
     // piece i of slab n lives at  i * plane + n * 1 KB
     const char* src = base + (int64_t)(wave * QDMA) * plane + ((int64_t)(li * NTW + MT)) * 1024;
-    char* dst = lds + slot * SLAB + wave * (SLAB / 4);
+    char* dst = lds + slot * SLAB + wave * (SLAB / NW);
 #pragma unroll
     for (int i = 0; i < QDMA; ++i) dma_1k(src + i * plane, dst + i * 1024, lane);
     ++issued;
@@ -195,7 +199,7 @@ struct SlabRing {
   // is for too much) — are outstanding.  Near the end of the sequence fewer younger slabs exist: drain everything.
   template <int EXTRA>
   __device__ __forceinline__ void wait_landed(int64_t g, bool extra_issued) {
-    constexpr int QDMA = SLAB / 4 / 1024;
+    constexpr int QDMA = SLAB / NW / 1024;
     constexpr int N = (R - 2) * QDMA;
     if (g + R - 1 > total) wait_vm<0>();           // (issue() has been skipping: fewer than R - 2 younger slabs)
     else if (EXTRA > 0 && N + EXTRA <= 63 && extra_issued) wait_vm<(N + EXTRA <= 63 ? N + EXTRA : N)>();
@@ -379,6 +383,268 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_fwd(const ChainParam
   }
   wait_vm<0>();
   CHAIN_DIAG_END(P);
+}
+
+
+// ============================================================================================================
+// Two waves per SIMD ("p8" kernels).  tools/ubench_ldsdma.hip: with ONE wave per SIMD a GEMM step of the chain
+// (64 MFMAs = 1024 matrix-pipe cycles) takes ~1800 cycles — bringing the 16 KB weight slab into LDS blocks the
+// waves for ~400 cycles (the CU moves ~40 B/clk whichever way the bytes are staged, and all four waves wait
+// on it at once), the slab's 16 fragment reads for ~260, the barrier for ~130 — and nothing overlaps any of it.
+// So the chain kernels run EIGHT waves per workgroup, two per SIMD, each with half the registers: a wave owns
+// 8 points (one half of a 16-point tile) x all quantities.  The 16 MFMA columns of a wave carry 8 points x 2
+// quantities: column = 8 * par + p8, group G holds quantities 2G (par 0) and 2G + 1 (par 1), so the jet of K1 = 4
+// is two column groups — 128 accumulator registers and 64 of B operand per wave instead of 256 + 128.  The 16-point
+// tile, its blocks in memory and the weight ring are unchanged (a workgroup is still four tiles = 64 points per
+// pass over the weights); the two waves of a tile are independent of each other.  Everything a point needs across
+// its quantities (tanh' for the tangents, the cross term of the adjoint) sits in the two lanes p8 and p8 + 8 of
+// the same wave: one DPP row rotate.
+constexpr int P8_WAVES = 8;
+constexpr int P8_THREADS = P8_WAVES * 64;
+
+__device__ __forceinline__ float dpp_ror8(float v) {      // lane i <- lane (i + 8) mod 16 of its row of 16
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+}
+// two stores (each a pair of quantity blocks) per step until the NGS = NG * NS stores of a layer are out: all in the
+// first half of the layer, so that they are old — retired, or nearly — when the batch boundary drains the queue
+template <int NGS>
+__host__ __device__ constexpr int p8_stores_at(int step) { return step >= 0 && 2 * step < NGS ? 2 : 0; }
+template <int NGS, int NTW, int R, int MT, bool CUR, bool PREV>
+__host__ __device__ constexpr int p8_younger_stores() {
+  int n = 0;
+  for (int j = 1; j <= R - 1; ++j) {
+    const int st = MT - j;
+    if (st >= 0) n += CUR ? p8_stores_at<NGS>(st) : 0;
+    else n += PREV ? p8_stores_at<NGS>(NTW + st) : 0;
+  }
+  return n;
+}
+
+// lanes 8..15 of every row of 16 take the value of lane - 8; lanes 0..7 keep theirs (bank mask 0b1100)
+__device__ __forceinline__ float dpp_hi_from_lo(float v) {
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x128, 0xf, 0xc, false));
+}
+
+// Roles inside a step.  Waves w and w + 4 share a SIMD (dispatch order); run in lockstep they would both stall on
+// their weight copies, then both on their fragment reads, then fight over the matrix pipe.  So the two halves of
+// the workgroup order a step differently: waves 0-3 ("early") issue their copies and stores and run the
+// activation of the PREVIOUS output tile first, then the step's MFMAs; waves 4-7 ("late") start with the MFMAs
+// and issue copies / stores / the activation of THIS output tile after them.  An output tile is final after its
+// own step (the loop is output-stationary: step MT multiplies the 16 x W slab of output tile MT with the whole
+// input jet), so the activation — the only vector-ALU-heavy part — always has a partner's MFMAs to hide behind,
+// only one or two accumulator tiles are ever live, and the next layer's operand is built piece by piece (`bn`).
+#ifndef PINN_P8_STAGGER
+#define PINN_P8_STAGGER 27         // s_sleep units (64 clocks each) per slot of the start-up spread, 256 slots
+#endif
+// Every workgroup loads its four tiles' a_1 and stores their a_L in one burst per tile batch; started together, all
+// 256 CUs burst together (64 MB at once, ~10 % of the kernel spent waiting on HBM while the matrix pipes idle) and
+// then leave HBM alone for the rest of the batch.  Starts are spread over about one batch's duration instead.
+__device__ __forceinline__ void p8_stagger() {
+  if (PINN_P8_STAGGER > 0) {
+    const int k = (blockIdx.x * 37) & 255;
+    for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(PINN_P8_STAGGER);
+  } else chain_stagger();
+}
+
+template <int NTW, int K1>
+__global__ __launch_bounds__(P8_THREADS, 2) void k_chain_fwd8(const ChainParams P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NS = NTW / 2;
+  constexpr int NG = (K1 + 1) / 2;
+  constexpr int SLAB = NS * 2 * 1024;
+  constexpr int QD = SLAB / P8_WAVES / 1024;
+  constexpr int R = CHAIN_RING_FWD;
+  constexpr int NST = NG * NS;                   // stores per wave and layer
+  static_assert(NST <= 2 * NTW && NST % 2 == 0, "two stores per step");
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef PINN_P8_ALL_EARLY
+  const bool early = true;
+#else
+  const bool early = wave < 4;
+#endif
+  const int q = lane >> 4, col = lane & 15, par = col >> 3, p8 = col & 7, half = wave & 1;
+  // byte offset of this lane inside the tile's jet: row 8 half + p8 of the block of quantity `par` (+ 2G per group)
+  const unsigned lvo = (unsigned)par * (NS * 1024) + (4u * (8u * half + p8) + q) * 16u;
+  // odd K1: the last group's par-1 lanes have no quantity — pushed out of the buffer's range (loads 0, stores dropped;
+  // only the per-lane offset is range-checked, the scalar block offset is not)
+  const unsigned lvo_last = ((K1 & 1) && par) ? 0x40000000u : lvo;
+  const int nh = P.L - 1;
+  const int64_t n_tb = (P.n_tiles + CHAIN_WAVES - 1) / CHAIN_WAVES;
+  const int64_t my_tb = (n_tb - blockIdx.x + gridDim.x - 1) / gridDim.x;
+  float* bias_lds = reinterpret_cast<float*>(smem + (R + 1) * SLAB);
+  for (int i = threadIdx.x; i < (P.L + 1) * 16 * NTW; i += P8_THREADS) bias_lds[i] = P.bias[i];
+  __syncthreads();
+  p8_stagger();
+#ifdef PINN_P8_PRIO_LATE
+  if (!early) __builtin_amdgcn_s_setprio(1);
+#endif
+  // The ring.  A wave's vector-memory operations retire in issue order, so "slab g has landed" is a vmcnt wait for
+  // at most the operations issued after its copies.  To make that number a compile-time constant of the step, every
+  // step issues the same operations whatever the layer: QD copies (past the last slab: of slab 0 into a spare slot
+  // nobody reads) and, for steps < NST, one jet store (layers with nothing to store use an empty buffer range:
+  // the store is dropped, and still counted).
+  SlabRing<NTW, SLAB, R, false, P8_WAVES> ring;
+  ring.init(P.Wf, P.w_plane, smem, nh, my_tb * nh * NTW, wave, lane);
+  auto issue = [&]() {
+    if (ring.issued < ring.total) ring.issue();
+    else {
+#pragma unroll
+      for (int i = 0; i < QD; ++i)
+        dma_1k((const char*)P.Wf + (int64_t)(wave * QD + i) * P.w_plane, smem + R * SLAB + (wave * QD + i) * 1024, lane);
+    }
+  };
+  for (int g0 = 0; g0 < R - 1; ++g0) issue();
+  CHAIN_DIAG_BEGIN;
+  constexpr int TILE_BYTES = K1 * NS * 1024;
+  bf8 bj[NG][NS], bn[NG][NS], bx[NG][NS];
+#pragma unroll
+  for (int G = 0; G < NG; ++G)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) bn[G][s] = bf8{0, 0, 0, 0, 0, 0, 0, 0};
+  // Tile batches.  A batch's a_1 is loaded into `bx` one layer ahead (at the start of the previous batch's last
+  // layer), its a_L is stored from `bn` at the start of the next batch: loads and stores retire in issue order, and a
+  // load issued right behind 16 KB of stores per wave would wait for all of them to reach HBM.
+  auto tile_of = [&](int64_t tb_, bool& live_) {
+    int64_t t_ = tb_ * CHAIN_WAVES + (wave >> 1);
+    live_ = tb_ < n_tb && t_ < P.n_tiles;
+    if (t_ >= P.n_tiles) t_ = P.n_tiles - 1;
+    return uniform64(t_) * (K1 * NS * 512);
+  };
+  auto load_a1 = [&](int64_t tbase_, bool any) {
+    const __amdgpu_buffer_rsrc_t a1r = jet_rsrc(P.A + tbase_, any ? TILE_BYTES : 0);
+#pragma unroll
+    for (int G = 0; G < NG; ++G)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) bx[G][s] = ld_blk(a1r, G == NG - 1 ? lvo_last : lvo, (2 * G * NS + s) * 1024);
+  };
+  auto store_aL = [&](int64_t tbase_, bool live_) {     // dead waves / before the first batch: dropped, counted
+    const __amdgpu_buffer_rsrc_t dstL = jet_rsrc(P.A + (int64_t)nh * P.jet_stride + tbase_, live_ ? TILE_BYTES : 0);
+#pragma unroll
+    for (int G = 0; G < NG; ++G)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) st_blk(dstL, G == NG - 1 ? lvo_last : lvo, (2 * G * NS + s) * 1024, bn[G][s]);
+  };
+  bool live = false, prev_live = false, next_live = false;
+  int64_t tbase = tile_of(blockIdx.x, live), prev_base = 0, next_base = 0;
+  load_a1(tbase, true);
+  for (int64_t tb = blockIdx.x; tb < n_tb; tb += gridDim.x) {
+#pragma unroll
+    for (int G = 0; G < NG; ++G)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) bj[G][s] = bx[G][s];
+    store_aL(prev_base, prev_live);
+    CHAIN_STAMP(6);
+    for (int l = 1; l <= nh; ++l) {
+      f4 accp[NG];
+      // a_l (l >= 2; a_1 is in memory already) goes out during this layer's steps, one block pair per step
+      const __amdgpu_buffer_rsrc_t dst = jet_rsrc(P.A + (int64_t)(l - 1) * P.jet_stride + tbase, live && P.spill && l >= 2 ? TILE_BYTES : 0);
+      const float* bl = bias_lds + l * (16 * NTW);
+      if (l == nh) {
+        next_base = tile_of(tb + gridDim.x, next_live);
+        load_a1(next_base, tb + gridDim.x < n_tb);
+      }
+      // activation of output tile M: the value lanes (group 0, par 0) take tanh(z + b); every other column of the
+      // point is a tangent and is scaled by the point's 1 - a^2 (one row rotate away for the par-1 lanes)
+      auto act = [&](auto m_, const f4 (&a)[NG]) {
+        constexpr int M = decltype(m_)::value, s = M / 2, h = M % 2;
+        const f4 b4 = *reinterpret_cast<const f4*>(bl + 16 * M + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float x = a[0][r];
+#ifdef PINN_P8_EXP_NOACT
+          const float av = x + b4[r];
+#else
+          const float av = tanh_bf(x + b4[r]);                  // meaningful on the par-0 lanes
+#endif
+          const float sv = dpp_hi_from_lo(fmaf(-av, av, 1.f));  // the point's 1 - a^2 on both of its lanes
+          bn[0][s][4 * h + r] = (__bf16)(par ? x * sv : av);
+#pragma unroll
+          for (int G = 1; G < NG; ++G) bn[G][s][4 * h + r] = (__bf16)(a[G][r] * sv);
+        }
+      };
+      auto side = [&](auto m_) {      // this step's copies and its share of the a_l stores
+        constexpr int M = decltype(m_)::value;
+#ifndef PINN_P8_EXP_NODMA
+        issue();
+#endif
+        if constexpr (2 * M < NST) {
+#pragma unroll
+          for (int i = 2 * M; i < 2 * M + 2; ++i)
+            st_blk(dst, i / NS == NG - 1 ? lvo_last : lvo, (2 * (i / NS) * NS + i % NS) * 1024, bj[i / NS][i % NS]);
+        }
+      };
+      static_for<0, NTW>([&](auto mt_) {
+        constexpr int MT = decltype(mt_)::value;
+        CHAIN_STAMP(5);
+        {
+          // younger than this step's slab: the copies of R - 2 slabs, the stores of the last R - 1 steps and, in
+          // the first R - 1 steps of a layer, what was issued at its start: the a_L stores of the previous batch
+          // (first layer), the a_1 loads of the next one (last layer)
+          constexpr int N = (R - 2) * QD + p8_younger_stores<NST, NTW, R, MT, true, true>();
+          static_assert(N + 2 * NST <= 63, "vmcnt range");
+          if (MT < R - 1 && (l == 1 || l == nh)) {
+            if (l == 1 && l == nh) wait_vm<N + 2 * NST>();
+            else wait_vm<N + NST>();
+          } else wait_vm<N>();
+        }
+        CHAIN_STAMP(0);
+#ifndef PINN_P8_EXP_NOBAR
+        __builtin_amdgcn_s_barrier();
+#endif
+        CHAIN_STAMP(1);
+        if (early) {
+          side(mt_);
+          CHAIN_STAMP(4);
+          if constexpr (MT > 0) act(std::integral_constant<int, (MT > 0 ? MT - 1 : 0)>{}, accp);
+          CHAIN_STAMP(3);
+        }
+        f4 accc[NG];
+#pragma unroll
+        for (int G = 0; G < NG; ++G) accc[G] = f4{0.f, 0.f, 0.f, 0.f};
+        const char* sl = ring.consume_ptr();
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#ifdef PINN_P8_EXP_NOLDS
+          const bf8 ahi = bj[0][s], alo = bj[NG - 1][s];
+#else
+          const bf8 ahi = *reinterpret_cast<const bf8*>(sl + s * 1024);
+          const bf8 alo = *reinterpret_cast<const bf8*>(sl + (NS + s) * 1024);
+#endif
+#pragma unroll
+          for (int G = 0; G < NG; ++G) {
+            accc[G] = mfma32(ahi, bj[G][s], accc[G]);
+            accc[G] = mfma32(alo, bj[G][s], accc[G]);
+          }
+        }
+        ring.consumed();
+        CHAIN_STAMP(2);
+        if (!early) {
+          side(mt_);
+          CHAIN_STAMP(4);
+          act(mt_, accc);
+          CHAIN_STAMP(3);
+        }
+#pragma unroll
+        for (int G = 0; G < NG; ++G) accp[G] = accc[G];
+      });
+      CHAIN_STAMP(5);
+      if (early) act(std::integral_constant<int, NTW - 1>{}, accp);
+      CHAIN_STAMP(3);
+      if (l < nh) {
+#pragma unroll
+        for (int G = 0; G < NG; ++G)
+#pragma unroll
+          for (int s = 0; s < NS; ++s) bj[G][s] = bn[G][s];
+      }
+      CHAIN_STAMP(6);
+    }
+    prev_base = tbase; prev_live = live;
+    tbase = next_base; live = next_live;
+  }
+  store_aL(prev_base, prev_live);
+  wait_vm<0>();
+  CHAIN_DIAG_END8(P);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -700,8 +966,123 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_wgrad(const ChainPar
   }
 }
 
+// The same with eight waves, two per SIMD (see k_chain_fwd8): the kernel streams 2 x 2 GB of jets per layer and its
+// unit time was set by the 8 copies per wave that open a unit — a wave alone on its SIMD issues nothing else
+// while a copy is being accepted — not by its 64 MFMAs.  Each of eight waves issues 4 copies and owns half the rows.
+template <int NTW, int K1>
+__global__ __launch_bounds__(P8_THREADS, 2) void k_chain_wgrad8(const ChainParams P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NS = NTW / 2;
+  constexpr int MTB = NTW / P8_WAVES;              // output tiles per wave: 2 (W = 256) or 1 (W = 128)
+  constexpr int KU = (K1 + 1) / 2;                 // k-steps per tile
+  constexpr int HALF = 2 * NS * 1024;              // bytes of one operand's two quantities
+  constexpr int UNIT = 2 * HALF;                   // [zbar c0 | zbar c1 | a c0 | a c1] x NS blocks
+  constexpr int UDMA = UNIT / 1024 / P8_WAVES;     // 1 KB copies per wave and unit
+  static_assert(UDMA * P8_WAVES * 1024 == UNIT && MTB >= 1, "unit split over 8 waves");
+  constexpr int RU = WG_UNITS;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool early = wave < 4;                     // SIMD partners (w, w + 4) order a unit differently: see k_chain_fwd8
+  const int i16 = lane & 15, qk = lane >> 4;
+  const int nh = P.L - 1;
+  const int li = blockIdx.x % nh, slice = blockIdx.x / nh;
+  if (slice >= P.n_slices) return;                 // (workgroup-uniform)
+  const int64_t t0 = P.n_tiles * slice / P.n_slices, t1 = P.n_tiles * (slice + 1) / P.n_slices;
+  const int64_t U = (t1 - t0) * KU;                // ring units this workgroup consumes
+  const unsigned short* Zl = P.Z + (int64_t)li * P.jet_stride;        // zbar_{li+1}
+  const unsigned short* Al = P.A + (int64_t)li * P.jet_stride;        // a_{li+1} (the layer's input)
+  auto issue_unit = [&](int64_t u) {
+    if (u >= U) return;
+    const int64_t t = t0 + u / KU;
+    const int ku = (int)(u % KU);
+    char* dst = smem + (int)(u % RU) * UNIT;
+    // copy j of this wave: j' = wave * UDMA + j in [0, 4 NS): operand (j' / (2 NS)), quantity 2 ku + (j' / NS) % 2, block j' % NS
+#pragma unroll
+    for (int j = 0; j < UDMA; ++j) {
+      const int jj = wave * UDMA + j;
+      const int op = jj / (2 * NS), cq = (jj / NS) & 1, s = jj % NS;
+      int c = 2 * ku + cq;
+      if (c >= K1) c = K1 - 1;                     // odd K1: the missing quantity is masked at the MFMA operand
+      const unsigned short* src = (op ? Al : Zl) + ((t * K1 + c) * NS + s) * 512;
+      dma_1k<PINN_CHAIN_JET_LD_AUX>(src, dst + jj * 1024, lane);
+    }
+  };
+  f4 dw[MTB][NTW];
+  float bs[MTB];
+#pragma unroll
+  for (int m = 0; m < MTB; ++m) {
+    bs[m] = 0.f;
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) dw[m][n] = f4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int u0 = 0; u0 < RU - 1; ++u0) issue_unit(u0);
+  // address of this lane's transposed-read element inside a quantity's NS-block region:
+  // rows = points 8 (qk & 1) + (i16 >> 2) (+4 for the second read), column quad = i16 & 3, at fixed (s, h)
+  const int tr_lane = (8 * (qk & 1) + (i16 >> 2)) * 64 + (i16 & 3) * 16;
+  const int cq_lane = qk >> 1;                     // which of the unit's two quantities this lane group contracts
+  CHAIN_DIAG_BEGIN;
+  for (int64_t u = 0; u < U; ++u) {
+    CHAIN_STAMP(2);
+    if (u + RU - 1 > U) wait_vm<0>();              // fewer than RU - 2 younger units exist: drain
+    else wait_vm<(RU - 2) * UDMA>();
+    CHAIN_STAMP(0);
+    __builtin_amdgcn_s_barrier();
+    CHAIN_STAMP(1);
+    if (early) issue_unit(u + RU - 1);
+    const char* ub = smem + (int)(u % RU) * UNIT;
+    const int ku = (int)(u % KU);
+    const bool qlive = 2 * ku + cq_lane < K1;      // odd K1: the padded quantity contributes nothing
+    const char* zb = ub + cq_lane * (NS * 1024) + tr_lane;
+    const char* ab = ub + HALF + cq_lane * (NS * 1024) + tr_lane;
+    bf8 za[MTB];
+#pragma unroll
+    for (int m = 0; m < MTB; ++m) {
+      const int MT = wave * MTB + m;
+      bf8 v = tr_operand(zb + (MT >> 1) * 1024 + (MT & 1) * 8);
+      if (!qlive) v = bf8{0, 0, 0, 0, 0, 0, 0, 0};
+      za[m] = v;
+      if (ku == 0 && qk < 2) {                     // bias gradient: sum over points of zbar's value quantity
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sacc += bf2f(v[j]);
+        bs[m] += sacc;
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+      const bf8 bb = tr_operand(ab + (n >> 1) * 1024 + (n & 1) * 8);
+#pragma unroll
+      for (int m = 0; m < MTB; ++m) dw[m][n] = mfma32(za[m], bb, dw[m][n]);
+    }
+    if (!early) issue_unit(u + RU - 1);
+  }
+  wait_vm<0>();
+  CHAIN_STAMP(2);
+  CHAIN_DIAG_END(P);
+  // one flush per wave into the flat torch-layout gradient: dW_l (out, in) row-major, then b_l
+  float* dWl = P.dW + P.w_off1 + (int64_t)li * P.w_per;
+  float* dbl = dWl + (int64_t)P.W * P.W;
+#pragma unroll
+  for (int m = 0; m < MTB; ++m) {
+    const int MT = wave * MTB + m;
+#pragma unroll
+    for (int n = 0; n < NTW; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * MT + 4 * qk + r, col = 16 * n + i16;
+        if (row < P.W && col < P.W)
+          __hip_atomic_fetch_add(dWl + (int64_t)row * P.W + col, dw[m][n][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    float tsum = bs[m];                            // lanes (i16, qk = 0, 1) hold points 0-7 / 8-15 of unit 16 MT + i16
+    tsum += __shfl_xor(tsum, 16, 64);
+    const int row = 16 * MT + i16;
+    if (qk == 0 && row < P.W) __hip_atomic_fetch_add(dbl + row, tsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 template <int NTW> int launch_chain_fwd(int K1, const ChainParams& P, int grid, hipStream_t s);
+template <int NTW> int launch_chain_fwd8(int K1, const ChainParams& P, int grid, hipStream_t s);
 template <int NTW> int launch_chain_bwd(int K1, const ChainParams& P, int grid, hipStream_t s);
 template <int NTW> int launch_chain_wgrad(int K1, const ChainParams& P, int grid, hipStream_t s);
+template <int NTW> int launch_chain_wgrad8(int K1, const ChainParams& P, int grid, hipStream_t s);
 
 }  // namespace pinn

@@ -236,7 +236,7 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
       C.w_off1 = n.w_off(1); C.w_per = (int64_t)n.W * n.W + n.W;
 #ifdef PINN_CHAIN_DIAG
       static unsigned long long* dbuf = nullptr;     // diagnostic build only (never shipped): 3 kernels x 8 phase sums
-      if (!dbuf) { (void)hipMalloc((void**)&dbuf, 24 * sizeof(unsigned long long)); }
+      if (!dbuf) { (void)hipMalloc((void**)&dbuf, 32 * sizeof(unsigned long long)); }
 #endif
       auto jetA = [&](int l) { return (float*)(base + w.jA + (int64_t)(l - 1) * w.jet_stride); };   // a_l, l = 1..L
       const int cgrid = (int)((Lp.n_tiles + CHAIN_WAVES - 1) / CHAIN_WAVES < w.grid ? (Lp.n_tiles + CHAIN_WAVES - 1) / CHAIN_WAVES : w.grid);
@@ -245,7 +245,11 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
 #ifdef PINN_CHAIN_DIAG
       C.diag = dbuf;
 #endif
+#ifdef PINN_CHAIN_FWD4
       if (nh > 0) { rc = launch_chain_fwd<NTW>(K1, C, cgrid, s); if (rc) break; }
+#else
+      if (nh > 0) { rc = launch_chain_fwd8<NTW>(K1, C, cgrid, s); if (rc) break; }
+#endif
       Lp.W = Wp + woff(L); Lp.b = Bp + L * g.WP; Lp.in_act = jetA(L); Lp.out_act = nullptr; Lp.g_out = gout;
       rc = launch_wide_fwd<NTW>(2, K1, prec, grad, P, Lp, grid, s); if (rc) break;
 #ifdef PINN_CHAIN_DIAG
@@ -281,12 +285,22 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
 #ifdef PINN_CHAIN_DIAG
         C.diag = dbuf + 16;
 #endif
+#ifdef PINN_CHAIN_WGRAD4
         rc = launch_chain_wgrad<NTW>(K1, C, C.n_slices * nh, s); if (rc) break;
+#else
+        rc = launch_chain_wgrad8<NTW>(K1, C, C.n_slices * nh, s); if (rc) break;
+#endif
 #ifdef PINN_CHAIN_DIAG
         {
-          unsigned long long h[24];
+          unsigned long long h[32];
           (void)hipStreamSynchronize(s);
           (void)hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost);
+          for (int k8 = 0; k8 < 2; ++k8) {
+            const unsigned long long* d = h + (k8 ? 24 : 0);
+            unsigned long long tot = 0; for (int i = 0; i < 8; ++i) tot += d[i];
+            fprintf(stderr, "CHAIN_DIAG fwd8 %s wave: wait %.1f%% barrier %.1f%% reads+mfma %.1f%% act %.1f%% copies+stores %.1f%% other %.1f%% tile-io %.1f%% | total %llu cycles\n",
+                    k8 ? "late" : "early", 100.0 * d[0] / tot, 100.0 * d[1] / tot, 100.0 * d[2] / tot, 100.0 * d[3] / tot, 100.0 * d[4] / tot, 100.0 * d[5] / tot, 100.0 * d[6] / tot, tot);
+          }
           const char* nm[3] = {"fwd", "bwd", "wgrad"};
           for (int k = 0; k < 3; ++k) {
             unsigned long long tot = 0; for (int i = 0; i < 8; ++i) tot += h[8 * k + i];

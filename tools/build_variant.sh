@@ -1,11 +1,8 @@
 #!/bin/bash
-# build_variant.sh NAME SRC "FLAGS": rebuild one translation unit with extra -D flags and link a
-# variant library pinn_depthestimation_amd/libpinn_hip_NAME.so (A/B runs: PINN_HIP_LIB=<that path>)
-set -e
-cd "$(dirname "$0")/../pinn_depthestimation_amd/csrc"
-NAME=$1; SRC=$2; FLAGS=$3
-OBJ=/tmp/variant_${NAME}_$(basename $SRC .hip).o
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -fno-gpu-rdc $FLAGS -c $SRC -o $OBJ
-OTHERS=$(ls *.o | grep -v "^$(basename $SRC .hip).o$")
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $OTHERS $OBJ -o ../libpinn_hip_${NAME}.so
-echo built ../libpinn_hip_${NAME}.so
+# build_variant.sh NAME "EXTRA FLAGS": an experimental copy of the library at pinn_depthestimation_amd/libpinn_NAME.so
+# (git-ignored; travels with gpurun; select it with PINN_HIP_LIB).
+R="$(cd "$(dirname "$0")/.." && pwd)"
+D=/tmp/variant_$1; rm -rf $D; mkdir -p $D; cp -r $R/pinn_depthestimation_amd/csrc $D/; rm -f $D/csrc/*.o; mkdir -p $D/include; cp $R/include/pinn_hip.h $D/include/
+sed -i 's#\.\./\.\./include/pinn_hip.h#../include/pinn_hip.h#' $D/csrc/common.h $D/csrc/Makefile
+make -C $D/csrc -j8 CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -fno-gpu-rdc $2" OUT=$R/pinn_depthestimation_amd/libpinn_$1.so > $D/build.log 2>&1 || { tail -20 $D/build.log; exit 1; }
+ls -la $R/pinn_depthestimation_amd/libpinn_$1.so

@@ -1,0 +1,25 @@
+"""Development check: bf16-mode loss from the forward-only pass vs from the loss+gradient pass vs fp64 oracle."""
+import os, sys
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch
+from oracle import pinn_oracle as O
+from pinn_depthestimation_amd import Engine, NetDesc, ResidualSpec
+from pinn_depthestimation_amd._lib import ENGINE_WIDE, PREC_BF16
+from tests.test_engine_gpu import oracle_loss_and_grad, rel_l2
+for (L, W) in ((2, 256), (3, 128), (3, 256)):
+    for N in (160, 70, 1237):
+        g = torch.Generator().manual_seed(4321)
+        params = O.init_params(O.layer_sizes(3, L, W, 4), "xavier", g)
+        X = torch.rand(N, 3, generator=g) * 2 - 1
+        desc = NetDesc(3, 4, L, W, (0, 1, 2), engine=ENGINE_WIDE, precision=PREC_BF16)
+        spec = ResidualSpec.from_names("Navier_Stokes", ("t", "x", "y"), desc.grad_cols, ("h", "z", "u", "v"))
+        l64, g64 = oracle_loss_and_grad(params, X, "Navier_Stokes", ("t", "x", "y"), ("h", "z", "u", "v"), desc.grad_cols, torch.float64)
+        flat, Xd = O.flatten(params).cuda(), X.cuda().contiguous()
+        scale = torch.full((spec.n_terms,), 1.0 / N).cuda()
+        eng = Engine(desc)
+        s0 = eng.residual_loss(spec, flat, Xd)
+        l0 = float((s0.double() * scale.double()).sum())
+        grad = torch.zeros(desc.n_params, device="cuda")
+        s1 = eng.residual_loss_grad(spec, scale, flat, Xd, grad)
+        l1 = float((s1.double() * scale.double()).sum())
+        print(f"ns_{L}x{W} N={N}: oracle {float(l64):.6e} fwd-only {l0:.6e} ({abs(l0-float(l64))/float(l64):.1e}) loss+grad {l1:.6e} ({abs(l1-float(l64))/float(l64):.1e}) grad err {rel_l2(grad.cpu(), g64):.1e}", flush=True)
