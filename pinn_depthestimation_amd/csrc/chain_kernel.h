@@ -426,6 +426,12 @@ __device__ __forceinline__ float dpp_hi_from_lo(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x128, 0xf, 0xc, false));
 }
 
+// Two units (r, r + 1) at a time: the arithmetic is packed fp32 (v_pk_mul / v_pk_fma), selections by lane are
+// multiplications with parf = (float)par — the vector ALU's issue port is shared with the MFMAs of the SIMD's other wave.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 dpp2_hi_from_lo(f2 v) { return f2{dpp_hi_from_lo(v[0]), dpp_hi_from_lo(v[1])}; }
+__device__ __forceinline__ f2 dpp2_ror8(f2 v) { return f2{dpp_ror8(v[0]), dpp_ror8(v[1])}; }
+__device__ __forceinline__ f2 bf2f2(bf8 v, int j) { return f2{bf2f(v[j]), bf2f(v[j + 1])}; }   // elements j, j + 1 (j even: one dword)
 // Roles inside a step.  Waves w and w + 4 share a SIMD (dispatch order); run in lockstep they would both stall on
 // their weight copies, then both on their fragment reads, then fight over the matrix pipe.  So the two halves of
 // the workgroup order a step differently: waves 0-3 ("early") issue their copies and stores and run the
@@ -469,6 +475,7 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_fwd8(const ChainParams 
   // odd K1: the last group's par-1 lanes have no quantity — pushed out of the buffer's range (loads 0, stores dropped;
   // only the per-lane offset is range-checked, the scalar block offset is not)
   const unsigned lvo_last = ((K1 & 1) && par) ? 0x40000000u : lvo;
+  const float parf = (float)par;
   const int nh = P.L - 1;
   const int64_t n_tb = (P.n_tiles + CHAIN_WAVES - 1) / CHAIN_WAVES;
   const int64_t my_tb = (n_tb - blockIdx.x + gridDim.x - 1) / gridDim.x;
@@ -550,17 +557,20 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_fwd8(const ChainParams 
         constexpr int M = decltype(m_)::value, s = M / 2, h = M % 2;
         const f4 b4 = *reinterpret_cast<const f4*>(bl + 16 * M + 4 * q);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float x = a[0][r];
-#ifdef PINN_P8_EXP_NOACT
-          const float av = x + b4[r];
-#else
-          const float av = tanh_bf(x + b4[r]);                  // meaningful on the par-0 lanes
-#endif
-          const float sv = dpp_hi_from_lo(fmaf(-av, av, 1.f));  // the point's 1 - a^2 on both of its lanes
-          bn[0][s][4 * h + r] = (__bf16)(par ? x * sv : av);
+        for (int r = 0; r < 4; r += 2) {                        // two units at a time, packed fp32 (see p8_adjoint)
+          const f2 x = f2{a[0][r], a[0][r + 1]};
+          const f2 e2 = (x + f2{b4[r], b4[r + 1]}) * 2.885390081777927f;      // 2 log2(e) (x + b)
+          const f2 ex = f2{__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])} + 1.f;
+          const f2 rc = f2{__builtin_amdgcn_rcpf(ex[0]), __builtin_amdgcn_rcpf(ex[1])};
+          const f2 av = 1.f - 2.f * rc;                         // tanh(x + b): meaningful on the par-0 lanes
+          const f2 sv = dpp2_hi_from_lo(1.f - av * av);         // the point's 1 - a^2 on both of its lanes
+          const f2 o0 = (x * sv - av) * parf + av;              // par 0: the value; par 1: tangent 1
+          bn[0][s][4 * h + r] = (__bf16)o0[0]; bn[0][s][4 * h + r + 1] = (__bf16)o0[1];
 #pragma unroll
-          for (int G = 1; G < NG; ++G) bn[G][s][4 * h + r] = (__bf16)(a[G][r] * sv);
+          for (int G = 1; G < NG; ++G) {
+            const f2 og = f2{a[G][r], a[G][r + 1]} * sv;
+            bn[G][s][4 * h + r] = (__bf16)og[0]; bn[G][s][4 * h + r + 1] = (__bf16)og[1];
+          }
         }
       };
       auto side = [&](auto m_) {      // this step's copies and its share of the a_l stores
@@ -844,6 +854,273 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_bwd(const ChainParam
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Reverse chain with eight waves (see k_chain_fwd8 for the layout and the step roles).  Per hidden matrix l = nh .. 1
+// the GEMM abar_l = W_l^T zbar_l runs on B = zbar_l (`bj`); output tile M of abar_l is final after step M and goes
+// through the activation adjoint with tile M of a_l at once, giving tile M of zbar_{l-1} (`bn`, the next GEMM's
+// operand; for l = 1: abar_1 itself, the kernel's output).  a_l arrives in k-step pieces (two output tiles) by LDS-DMA
+// into a four-slot staging area, four steps ahead of its use; the two waves of a tile copy half of the tile's blocks
+// each.  zbar_l goes out from `bj` during its own GEMM (weight-gradient operand).
+constexpr int CHAIN_RING8 = 5;             // weight slabs in the LDS ring of k_chain_bwd8 (beside 4 staging slots)
+constexpr int B8_STAGES = 4;
+
+// vector-memory operations one wave issues at GEMM step `step` of the reverse chain (any layer; negative steps are the
+// previous layer's): QD slab copies, then NG staging copies (even steps), then two zbar stores (first half).
+template <int QD, int NG, int NST, int NTW>
+__host__ __device__ constexpr int b8_stores_at(int step) { const int m = ((step % NTW) + NTW) % NTW; return 2 * m < NST ? 2 : 0; }
+template <int QD, int NG, int NST, int NTW>
+__host__ __device__ constexpr int b8_ops_at(int step) {
+  const int m = ((step % NTW) + NTW) % NTW;
+  return QD + ((m & 1) ? 0 : NG) + b8_stores_at<QD, NG, NST, NTW>(step);
+}
+template <int QD, int NG, int NST, int NTW>
+__host__ __device__ constexpr int b8_ops_in(int m0, int m1) { int n = 0; for (int m = m0; m < m1; ++m) n += b8_ops_at<QD, NG, NST, NTW>(m); return n; }
+// operations younger than the slab copies issued at step MT - (R - 1) / than the staging copies issued at step MT - 4
+template <int QD, int NG, int NST, int NTW, int R>
+__host__ __device__ constexpr int b8_younger_slab(int MT) {
+  return b8_ops_at<QD, NG, NST, NTW>(MT - (R - 1)) - QD + b8_ops_in<QD, NG, NST, NTW>(MT - (R - 2), MT);
+}
+template <int QD, int NG, int NST, int NTW>
+__host__ __device__ constexpr int b8_younger_stage(int MT) {
+  return b8_stores_at<QD, NG, NST, NTW>(MT - 4) + b8_ops_in<QD, NG, NST, NTW>(MT - 3, MT);
+}
+
+// Activation adjoint of one unit of one point.  The lane holds quantity 2G + par of group G: ab = abar, at = the jet of
+// a (at[0] on the par-0 lanes is the value a itself).  zbar_c = abar_c (1 - a^2) for the tangents;
+// zbar_0 = (1 - a^2) abar_0 - 2 a sum_c abar_c a_c   (tanh'' = -2 a (1 - a^2), fused_kernel.h activate_adjoint).
+template <int NG>
+__device__ __forceinline__ void p8_adjoint(const f2 (&ab)[NG], const f2 (&at)[NG], float parf, f2 (&out)[NG]) {
+  const f2 a = dpp2_hi_from_lo(at[0]);
+  const f2 sv = 1.f - a * a;
+  f2 part = (ab[0] * at[0]) * parf;
+#pragma unroll
+  for (int G = 1; G < NG; ++G) part = ab[G] * at[G] + part;
+  const f2 cross = part + dpp2_ror8(part);
+  const f2 t = ab[0] * sv;
+  out[0] = ((-2.f * (1.f - parf)) * a) * cross + t;       // par 1: tangent 1, abar sv; par 0: the value's adjoint
+#pragma unroll
+  for (int G = 1; G < NG; ++G) out[G] = ab[G] * sv;
+}
+
+template <int NTW, int K1>
+__global__ __launch_bounds__(P8_THREADS, 2) void k_chain_bwd8(const ChainParams P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NS = NTW / 2;
+  constexpr int NG = (K1 + 1) / 2;
+  constexpr bool LO = PINN_CHAIN_BWD_LO != 0;
+  constexpr int SLAB = NS * (LO ? 2 : 1) * 1024;     // the hi pieces are the first NS planes of a packed slab
+  constexpr int QD = SLAB / P8_WAVES / 1024;
+  static_assert(QD >= 1 && QD * P8_WAVES * 1024 == SLAB, "slab split over 8 waves");
+  constexpr int R = CHAIN_RING8;
+  constexpr int NST = NG * NS;
+  static_assert(NST % 2 == 0 && NST <= 2 * NTW && NS % 2 == 0, "store / prologue schedule");
+  constexpr int TILE_STAGE = 2 * NG * 1024;          // per tile and piece: one block per quantity (odd K1: one spare)
+  constexpr int STAGE_BYTES = CHAIN_WAVES * TILE_STAGE;
+  constexpr int TILE_BYTES = K1 * NS * 1024;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool early = wave < 4;
+  const int q = lane >> 4, col = lane & 15, par = col >> 3, p8 = col & 7, half = wave & 1;
+  const unsigned lrow = (4u * (8u * half + p8) + q) * 16u;
+  const unsigned lvo = (unsigned)par * (NS * 1024) + lrow;
+  const unsigned lvo_last = ((K1 & 1) && par) ? 0x40000000u : lvo;
+  const float parf = (float)par;
+  const float live_col = ((K1 & 1) && par) ? 0.f : 1.f;   // last group, odd K1: this lane's column carries no quantity
+  const int nh = P.L - 1;
+  const int64_t n_tb = (P.n_tiles + CHAIN_WAVES - 1) / CHAIN_WAVES;
+  const int64_t my_tb = (n_tb - blockIdx.x + gridDim.x - 1) / gridDim.x;
+  p8_stagger();
+  SlabRing<NTW, SLAB, R, true, P8_WAVES> ring;     // slab order: layers nh-1 .. 0 (descending), tiles 0 .. NTW-1
+  ring.init(P.WTf, P.w_plane, smem, nh, my_tb * nh * NTW, wave, lane);
+  const __amdgpu_buffer_rsrc_t nowhere = jet_rsrc(P.G1, 0);
+  auto issue = [&]() {                              // constant operation count per step (see k_chain_fwd8)
+    if (ring.issued < ring.total) ring.issue();
+    else {
+#pragma unroll
+      for (int i = 0; i < QD; ++i) st_blk(nowhere, lvo, 0, bf8{0, 0, 0, 0, 0, 0, 0, 0});
+    }
+  };
+  char* stage = smem + R * SLAB + (wave >> 1) * TILE_STAGE;       // this wave's tile inside a staging slot
+  // piece s of the jet at a_tile: this wave copies the blocks of quantities half * NG .. + NG - 1 of its tile
+  auto stage_piece = [&](const unsigned short* a_tile, int s, int slot) {
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const int c = half * NG + i;
+      const int cs = c < K1 ? c : K1 - 1;           // (odd K1: the spare block gets a copy of the last quantity; never used)
+      dma_1k<PINN_CHAIN_JET_LD_AUX>(a_tile + (cs * NS + s) * 512, stage + slot * STAGE_BYTES + c * 1024, lane);
+    }
+  };
+  auto read_piece = [&](int slot, bf8 (&ap)[NG]) {
+#pragma unroll
+    for (int G = 0; G < NG; ++G)
+      ap[G] = *reinterpret_cast<const bf8*>(stage + slot * STAGE_BYTES + (2 * G + par) * 1024 + lrow);
+  };
+  for (int g0 = 0; g0 < R - 1; ++g0) issue();
+  CHAIN_DIAG_BEGIN;
+  bf8 bj[NG][NS], bn[NG][NS];
+#pragma unroll
+  for (int G = 0; G < NG; ++G)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) bn[G][s] = bf8{0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t prev_base = 0;
+  bool prev_live = false;
+  for (int64_t tb = blockIdx.x; tb < n_tb; tb += gridDim.x) {
+    int64_t t = tb * CHAIN_WAVES + (wave >> 1);
+    const bool live = t < P.n_tiles;
+    if (!live) t = P.n_tiles - 1;
+    const int64_t tbase = uniform64(t) * (K1 * NS * 512);
+    // ---- batch prologue: zbar_nh = adjoint(abar_L, a_L), both from memory, in two halves of the k-steps.  Order of
+    // the second half: loads, the staging copies of the first two pieces of a_nh, the stores of the PREVIOUS batch's
+    // abar_1 (still in `bn`), then the arithmetic — nothing a wait of this batch covers is younger than the stores.
+    {
+      const __amdgpu_buffer_rsrc_t glr = jet_rsrc(P.GL + tbase, TILE_BYTES);
+      const __amdgpu_buffer_rsrc_t alr = jet_rsrc(P.A + (int64_t)nh * P.jet_stride + tbase, TILE_BYTES);
+      const unsigned short* a_nh = P.A + (int64_t)(nh - 1) * P.jet_stride + tbase;
+      static_for<0, 2>([&](auto hh_) {
+        constexpr int S0 = decltype(hh_)::value * (NS / 2);
+        bf8 gv[NG][NS / 2], av[NG][NS / 2];
+#pragma unroll
+        for (int G = 0; G < NG; ++G)
+#pragma unroll
+          for (int s = 0; s < NS / 2; ++s) {
+            gv[G][s] = ld_blk(glr, G == NG - 1 ? lvo_last : lvo, (2 * G * NS + S0 + s) * 1024);
+            av[G][s] = ld_blk(alr, G == NG - 1 ? lvo_last : lvo, (2 * G * NS + S0 + s) * 1024);
+          }
+        if constexpr (S0 > 0) {
+          stage_piece(a_nh, 0, 0);
+          stage_piece(a_nh, 1, 1);
+          const __amdgpu_buffer_rsrc_t g1r = jet_rsrc(P.G1 + prev_base, prev_live ? TILE_BYTES : 0);
+#pragma unroll
+          for (int G = 0; G < NG; ++G)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) st_blk(g1r, G == NG - 1 ? lvo_last : lvo, (2 * G * NS + s) * 1024, bn[G][s]);
+        }
+#pragma unroll
+        for (int s = 0; s < NS / 2; ++s)
+#pragma unroll
+          for (int j = 0; j < 8; j += 2) {
+            f2 ab[NG], at[NG], o[NG];
+#pragma unroll
+            for (int G = 0; G < NG; ++G) { ab[G] = bf2f2(gv[G][s], j); at[G] = bf2f2(av[G][s], j); }
+            p8_adjoint<NG>(ab, at, parf, o);
+#pragma unroll
+            for (int G = 0; G < NG; ++G) { bj[G][S0 + s][j] = (__bf16)o[G][0]; bj[G][S0 + s][j + 1] = (__bf16)o[G][1]; }
+          }
+      });
+    }
+    prev_base = tbase; prev_live = live;
+    CHAIN_STAMP(6);
+    for (int l = nh; l >= 1; --l) {
+      f4 accp[NG];
+      bf8 ap[2][NG];                                // pieces of a_l: even / odd piece numbers
+      const __amdgpu_buffer_rsrc_t zdst = jet_rsrc(P.Z + (int64_t)(l - 1) * P.jet_stride + tbase, live ? TILE_BYTES : 0);
+      const unsigned short* a_cur = P.A + (int64_t)(l - 1) * P.jet_stride + tbase;                  // a_l
+      const unsigned short* a_nxt = P.A + (int64_t)(l >= 2 ? l - 2 : 0) * P.jet_stride + tbase;     // a_{l-1} (l = 1: unused copies)
+      // adjoint of output tile M (l >= 2), or abar_1 as it is (l = 1)
+      auto act = [&](auto m_, const f4 (&a)[NG]) {
+        constexpr int M = decltype(m_)::value, s = M / 2, h = M % 2;
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          f2 ab[NG], at[NG], o[NG];
+#pragma unroll
+          for (int G = 0; G < NG; ++G) { ab[G] = f2{a[G][r], a[G][r + 1]}; at[G] = bf2f2(ap[s & 1][G], 4 * h + r); }
+          if constexpr (K1 & 1) at[NG - 1] = at[NG - 1] * live_col;      // (the spare staging block holds a copy, not zeros)
+          if (l >= 2) p8_adjoint<NG>(ab, at, parf, o);
+          else {
+#pragma unroll
+            for (int G = 0; G < NG; ++G) o[G] = ab[G];
+          }
+#pragma unroll
+          for (int G = 0; G < NG; ++G) { bn[G][s][4 * h + r] = (__bf16)o[G][0]; bn[G][s][4 * h + r + 1] = (__bf16)o[G][1]; }
+        }
+      };
+      auto side = [&](auto m_) {
+        constexpr int M = decltype(m_)::value;
+        issue();
+        if constexpr ((M & 1) == 0) {
+          if constexpr (M + 4 < NTW) stage_piece(a_cur, (M + 4) / 2, ((M + 4) / 2) % B8_STAGES);
+          else stage_piece(a_nxt, (M + 4 - NTW) / 2, ((M + 4 - NTW) / 2) % B8_STAGES);
+        }
+        if constexpr (2 * M < NST) {
+#pragma unroll
+          for (int i = 2 * M; i < 2 * M + 2; ++i)
+            st_blk(zdst, i / NS == NG - 1 ? lvo_last : lvo, (2 * (i / NS) * NS + i % NS) * 1024, bj[i / NS][i % NS]);
+        }
+      };
+      static_for<0, NTW>([&](auto mt_) {
+        constexpr int MT = decltype(mt_)::value;
+        CHAIN_STAMP(5);
+        {
+          constexpr int NSL = b8_younger_slab<QD, NG, NST, NTW, R>(MT);
+          constexpr int NSG = b8_younger_stage<QD, NG, NST, NTW>(MT);
+          constexpr int N = (MT & 1) ? NSL : (NSG < NSL ? NSG : NSL);
+          // first layer of a batch, first four steps: the slabs were copied before the prologue, whose load waits
+          // retired them; the staging copies of pieces 0 and 1 and the stores sit in the prologue
+          constexpr int NF = MT == 0 ? NG + NST
+                           : MT == 2 ? NST + b8_ops_in<QD, NG, NST, NTW>(0, 2)
+                                     : 2 * NG + NST + b8_ops_in<QD, NG, NST, NTW>(0, MT);
+          static_assert(N <= 63 && (MT >= 4 || NF <= 63), "vmcnt range");
+          if (MT < 4 && l == nh) wait_vm<(MT < 4 ? NF : 0)>();
+          else wait_vm<N>();
+        }
+        CHAIN_STAMP(0);
+        __builtin_amdgcn_s_barrier();
+        CHAIN_STAMP(1);
+        if constexpr ((MT & 1) == 0) read_piece((MT / 2) % B8_STAGES, ap[(MT / 2) & 1]);
+        if (early) {
+          side(mt_);
+          CHAIN_STAMP(4);
+          if constexpr (MT > 0) act(std::integral_constant<int, (MT > 0 ? MT - 1 : 0)>{}, accp);
+          CHAIN_STAMP(3);
+        }
+        f4 accc[NG];
+#pragma unroll
+        for (int G = 0; G < NG; ++G) accc[G] = f4{0.f, 0.f, 0.f, 0.f};
+        const char* sl = ring.consume_ptr();
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const bf8 ahi = *reinterpret_cast<const bf8*>(sl + s * 1024);
+#pragma unroll
+          for (int G = 0; G < NG; ++G) accc[G] = mfma32(ahi, bj[G][s], accc[G]);
+          if constexpr (LO) {
+            const bf8 alo = *reinterpret_cast<const bf8*>(sl + (NS + s) * 1024);
+#pragma unroll
+            for (int G = 0; G < NG; ++G) accc[G] = mfma32(alo, bj[G][s], accc[G]);
+          }
+        }
+        ring.consumed();
+        CHAIN_STAMP(2);
+        if (!early) {
+          side(mt_);
+          CHAIN_STAMP(4);
+          act(mt_, accc);
+          CHAIN_STAMP(3);
+        }
+#pragma unroll
+        for (int G = 0; G < NG; ++G) accp[G] = accc[G];
+      });
+      CHAIN_STAMP(5);
+      if (early) act(std::integral_constant<int, NTW - 1>{}, accp);
+      CHAIN_STAMP(3);
+      if (l >= 2) {
+#pragma unroll
+        for (int G = 0; G < NG; ++G)
+#pragma unroll
+          for (int s = 0; s < NS; ++s) bj[G][s] = bn[G][s];
+      }
+      CHAIN_STAMP(5);
+    }
+  }
+  {   // abar_1 of the last batch
+    const __amdgpu_buffer_rsrc_t g1r = jet_rsrc(P.G1 + prev_base, prev_live ? TILE_BYTES : 0);
+#pragma unroll
+    for (int G = 0; G < NG; ++G)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) st_blk(g1r, G == NG - 1 ? lvo_last : lvo, (2 * G * NS + s) * 1024, bn[G][s]);
+  }
+  wait_vm<0>();
+  CHAIN_DIAG_END8(P);
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Weight gradient of all hidden matrices in one launch.  Workgroup b -> (layer li = b % nh, slice b / nh); wave w
 // owns output-unit tiles [w * MTB, (w + 1) * MTB) x all NTW input tiles of dW_l in registers.  The contraction
 // runs over (quantity c, point p): per tile two k-steps of 32 — k-step u holds quantities 2u, 2u + 1 (lane group
@@ -1082,6 +1359,7 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_wgrad8(const ChainParam
 template <int NTW> int launch_chain_fwd(int K1, const ChainParams& P, int grid, hipStream_t s);
 template <int NTW> int launch_chain_fwd8(int K1, const ChainParams& P, int grid, hipStream_t s);
 template <int NTW> int launch_chain_bwd(int K1, const ChainParams& P, int grid, hipStream_t s);
+template <int NTW> int launch_chain_bwd8(int K1, const ChainParams& P, int grid, hipStream_t s);
 template <int NTW> int launch_chain_wgrad(int K1, const ChainParams& P, int grid, hipStream_t s);
 template <int NTW> int launch_chain_wgrad8(int K1, const ChainParams& P, int grid, hipStream_t s);
 

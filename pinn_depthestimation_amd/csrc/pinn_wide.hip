@@ -223,6 +223,12 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
     if (hipMemsetAsync(P.wg_sums + (int64_t)Lp.sums_slot * MAX_SUMS, 0, (size_t)w.grid * MAX_SUMS * 4, s) != hipSuccess) {
       set_error("hipMemsetAsync failed"); return PINN_ERR_LAUNCH;
     }
+#ifndef PINN_THIN_MULT
+#define PINN_THIN_MULT 1
+#endif
+    // bf16 mode's first / last layer kernels stream 2 GB of jets each and are latency-bound at one workgroup per CU:
+    // workgroups per CU where their register use allows it
+    constexpr int THIN_WGRAD_LAST_WGS = PINN_THIN_MULT > 1 ? 4 : 1, THIN_BWD_FIRST_WGS = PINN_THIN_MULT > 1 ? 2 : 1, THIN_WGRAD_FIRST_WGS = PINN_THIN_MULT > 1 ? 2 : 1;
     if (chain) {
       // ---- bf16 mode: first / last layer on this file's kernels (fp32 MFMA on the thin matrices, chain-layout
       // bf16 jets), the L - 1 hidden matrices on the three chain kernels (chain_kernel.h) ----
@@ -236,7 +242,7 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
       C.w_off1 = n.w_off(1); C.w_per = (int64_t)n.W * n.W + n.W;
 #ifdef PINN_CHAIN_DIAG
       static unsigned long long* dbuf = nullptr;     // diagnostic build only (never shipped): 3 kernels x 8 phase sums
-      if (!dbuf) { (void)hipMalloc((void**)&dbuf, 32 * sizeof(unsigned long long)); }
+      if (!dbuf) { (void)hipMalloc((void**)&dbuf, 48 * sizeof(unsigned long long)); }
 #endif
       auto jetA = [&](int l) { return (float*)(base + w.jA + (int64_t)(l - 1) * w.jet_stride); };   // a_l, l = 1..L
       const int cgrid = (int)((Lp.n_tiles + CHAIN_WAVES - 1) / CHAIN_WAVES < w.grid ? (Lp.n_tiles + CHAIN_WAVES - 1) / CHAIN_WAVES : w.grid);
@@ -266,19 +272,27 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
       // output layer: dW_L = G . a_L^T ; abar_L = W_L^T G (bf16, chain layout)
       Lp.g_in = gout; Lp.in_act = jetA(L); Lp.in_d = n.in_dim(L); Lp.out_d = n.out_dim(L);
       Lp.dW = rq->grad + n.w_off(L); Lp.db = rq->grad + n.b_off(L);
-      rc = launch_wide_wgrad<NTW>(2, K1, prec, P, Lp, w.grid, s); if (rc) break;
+      rc = launch_wide_wgrad<NTW>(2, K1, prec, P, Lp, w.grid * THIN_WGRAD_LAST_WGS, s); if (rc) break;
       Lp.W = WTp + woff(L); Lp.g_out = (float*)C.GL;
       rc = launch_wide_bwd<NTW>(2, K1, prec, P, Lp, grid, s); if (rc) break;
 #ifdef PINN_CHAIN_DIAG
       C.diag = dbuf + 8;
 #endif
+#ifdef PINN_CHAIN_BWD4
       if (nh > 0) { rc = launch_chain_bwd<NTW>(K1, C, cgrid, s); if (rc) break; }
+#else
+      if (nh > 0) { rc = launch_chain_bwd8<NTW>(K1, C, cgrid, s); if (rc) break; }
+#endif
       // first layer: zbar_0 = adjoint(abar_1, a_1), in place over abar_1; dW_0 = zbar_0 . (x, e_j)^T
       Lp.g_in = (float*)C.G1; Lp.in_act = jetA(1); Lp.g_out = nullptr; Lp.W = nullptr; Lp.z_out = (float*)C.G1;
-      rc = launch_wide_bwd<NTW>(0, K1, prec, P, Lp, grid, s); if (rc) break;
+      {
+        const int64_t wgs = (Lp.n_tiles + WIDE_WAVES - 1) / WIDE_WAVES;
+        const int g2 = (int)(wgs < (int64_t)w.grid * THIN_BWD_FIRST_WGS ? wgs : (int64_t)w.grid * THIN_BWD_FIRST_WGS);
+        rc = launch_wide_bwd<NTW>(0, K1, prec, P, Lp, g2, s); if (rc) break;
+      }
       Lp.g_in = (float*)C.G1; Lp.in_act = nullptr; Lp.in_d = n.in_dim(0); Lp.out_d = n.out_dim(0);
       Lp.dW = rq->grad + n.w_off(0); Lp.db = rq->grad + n.b_off(0);
-      rc = launch_wide_wgrad<NTW>(0, K1, prec, P, Lp, w.grid, s); if (rc) break;
+      rc = launch_wide_wgrad<NTW>(0, K1, prec, P, Lp, w.grid * THIN_WGRAD_FIRST_WGS, s); if (rc) break;
       if (nh > 0) {
         C.n_slices = w.grid / nh > 0 ? w.grid / nh : 1;
         if ((int64_t)C.n_slices > Lp.n_tiles) C.n_slices = (int)Lp.n_tiles;
@@ -292,14 +306,14 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
 #endif
 #ifdef PINN_CHAIN_DIAG
         {
-          unsigned long long h[32];
+          unsigned long long h[48];
           (void)hipStreamSynchronize(s);
           (void)hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost);
-          for (int k8 = 0; k8 < 2; ++k8) {
-            const unsigned long long* d = h + (k8 ? 24 : 0);
+          for (int k8 = 0; k8 < 4; ++k8) {
+            const unsigned long long* d = h + (k8 == 0 ? 0 : k8 == 1 ? 24 : k8 == 2 ? 8 : 32);
             unsigned long long tot = 0; for (int i = 0; i < 8; ++i) tot += d[i];
-            fprintf(stderr, "CHAIN_DIAG fwd8 %s wave: wait %.1f%% barrier %.1f%% reads+mfma %.1f%% act %.1f%% copies+stores %.1f%% other %.1f%% tile-io %.1f%% | total %llu cycles\n",
-                    k8 ? "late" : "early", 100.0 * d[0] / tot, 100.0 * d[1] / tot, 100.0 * d[2] / tot, 100.0 * d[3] / tot, 100.0 * d[4] / tot, 100.0 * d[5] / tot, 100.0 * d[6] / tot, tot);
+            fprintf(stderr, "CHAIN_DIAG %s %s wave: wait %.1f%% barrier %.1f%% reads+mfma %.1f%% act %.1f%% copies+stores %.1f%% other %.1f%% tile-io %.1f%% | total %llu cycles\n",
+                    k8 < 2 ? "fwd8" : "bwd8", (k8 & 1) ? "late" : "early", 100.0 * d[0] / tot, 100.0 * d[1] / tot, 100.0 * d[2] / tot, 100.0 * d[3] / tot, 100.0 * d[4] / tot, 100.0 * d[5] / tot, 100.0 * d[6] / tot, tot);
           }
           const char* nm[3] = {"fwd", "bwd", "wgrad"};
           for (int k = 0; k < 3; ++k) {

@@ -13,9 +13,14 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 out = []
 for r in rows:
     n = r["Name"]
+    if "k_chain_pack" in n:
+        continue
     if "k_chain" in n:
         short = n.split("k_chain_")[1].split("<")[0].split("I")[0]
-        out.append("%s %.2f ms" % (short, float(r["AverageNs"]) / 1e6))
+        out.append("%s %.2f" % (short, float(r["AverageNs"]) / 1e6))
+    elif "k_wide_" in n and float(r["AverageNs"]) > 2e5:
+        short = n.split("k_wide_")[1].split("(")[0].replace(" ", "")
+        out.append("%s %.2f" % (short, float(r["AverageNs"]) / 1e6))
 print("; ".join(out))
 PY
 )"
