@@ -2,17 +2,17 @@
 // "bf16 MFMA with fp32 residual accumulate"): the W x W hidden layers of the network are walked by THREE
 // kernels per point chunk instead of three launches per layer (wide_kernel.h, which stays the fp32 path):
 //
-//   k_chain_fwd    per 16-point tile and wave: a_1 -> a_2 -> ... -> a_L through all hidden layers; the jet
-//                  (value + k tangents) lives in registers as the NEXT layer's MFMA B operand, the weights
-//                  stream through an LDS ring shared by the workgroup's four waves (one LDS-DMA copy per
-//                  workgroup instead of one L2 read per wave); every a_l is written once for the reverse sweep.
+//   k_chain_fwd8   per 16-point tile: a_1 -> a_2 -> ... -> a_L through all hidden layers; the jet (value + k
+//                  tangents) lives in registers as the NEXT layer's MFMA B operand, the weights stream through an
+//                  LDS ring shared by the workgroup (one LDS-DMA copy per workgroup instead of one L2 read per wave);
+//                  every a_l is written once for the reverse sweep.  Eight waves, two per SIMD, a tile per wave pair.
 //   k_chain_bwd    the reverse chain: abar_L -> zbar_{L-1} -> abar_{L-1} -> ... -> abar_1 with the adjoint kept in
 //                  the fp32 accumulators between layers (never rounded to bf16, never through HBM); reads each
-//                  a_l once, writes each zbar_l once.
-//   k_chain_wgrad  dW_l = sum_points zbar_l (x) a_l for ALL hidden layers in one launch: a workgroup owns one
+//                  a_l once, writes each zbar_l once.  Four waves, a tile per wave.
+//   k_chain_wgrad8 dW_l = sum_points zbar_l (x) a_l for ALL hidden layers in one launch: a workgroup owns one
 //                  layer's whole 256 x 256 gradient in registers for its slice of the points (dW-stationary),
 //                  streams zbar_l / a_l tiles through an LDS ring by LDS-DMA and takes the MFMA operands
-//                  out of it with ds_read_b64_tr_b16 (the hardware transpose: contraction over points).
+//                  out of it with ds_read_b64_tr_b16 (the hardware transpose: contraction over points).  Eight waves.
 //
 // HBM traffic per point and hidden layer: 2 KB (a written) + 2 + 2 (a, zbar in the reverse chain) + 4 (weight
 // gradient) = 10 KB, against 16 KB for one launch per layer; weights come from L2 once per workgroup and layer.
@@ -26,8 +26,8 @@
 // Precision: bf16 operands, fp32 accumulate.  Jets (a_l, zbar_l) carry 8 significant bits.  The WEIGHTS are
 // split hi + lo (two bf16, two MFMAs): rounding the weights themselves to bf16 moves this loss by 1.1e-2 and its
 // gradient by 1.2e-1 (measured on the reference's 12 x 256 golden, tests/test_config3_gpu.py — a PINN's loss
-// surface is stiff), the jets' rounding by 1.8e-3 / 3.8e-3; the kernels are bound by HBM, not by the matrix pipe,
-// so the second MFMA is free.
+// surface is stiff), the jets' rounding by 1.8e-3 / 3.8e-3.  The second MFMA doubles the matrix-pipe work of the two
+// chain kernels; neither is bound by it (they are bound by what happens between their MFMAs).
 //
 // Jet storage ("chain layout", bf16): block (tile t, quantity c, k-step s) = 1 KB = [point p (16)][32 units], the
 // 32 units ordered q, h, r — lane (p, q)'s 16 bytes are its B operand of k-step s, at byte (4p + q) * 16.  One
@@ -265,127 +265,6 @@ __host__ __device__ constexpr int chain_pf_pieces(int NTW, int K1) {   // k-step
 
 // ------------------------------------------------------------------------------------------------------------
 // Forward chain.  Weight slab (layer l, output tile MT) = [hi | lo][k-step s][lane][8 bf16]: NS * 2 KB.
-template <int NTW, int K1>
-__global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_fwd(const ChainParams P) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NS = NTW / 2;
-  constexpr int SLAB = NS * 2 * 1024;              // bytes
-  constexpr int R = CHAIN_RING_FWD;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int q = lane >> 4;
-  const unsigned lpos = (4u * (lane & 15) + q) * 16u;  // BYTE offset of this lane inside a jet block
-  const int nh = P.L - 1;                          // hidden matrices
-  const int64_t n_tb = (P.n_tiles + CHAIN_WAVES - 1) / CHAIN_WAVES;
-  const int64_t my_tb = (n_tb - blockIdx.x + gridDim.x - 1) / gridDim.x;   // tile batches of this workgroup
-  // biases of every layer in LDS behind the ring: as ordinary global loads next to LDS-DMA traffic each of the 16
-  // bias reads of an activation phase made the compiler drain the whole vector-memory queue (weight copies
-  // included) before its first use
-  float* bias_lds = reinterpret_cast<float*>(smem + R * SLAB);
-  for (int i = threadIdx.x; i < (P.L + 1) * 16 * NTW; i += CHAIN_THREADS) bias_lds[i] = P.bias[i];
-  __syncthreads();
-  chain_stagger();
-  SlabRing<NTW, SLAB, R, false> ring;
-  ring.init(P.Wf, P.w_plane, smem, nh, my_tb * nh * NTW, wave, lane);
-  for (int g0 = 0; g0 < R - 1; ++g0) ring.issue();
-  int64_t g = 0;
-  bool burst = false;                              // did this wave just write a_L (K1 * NS stores behind the last GEMM)?
-  CHAIN_DIAG_BEGIN;
-  for (int64_t tb = blockIdx.x; tb < n_tb; tb += gridDim.x) {
-    int64_t t = tb * CHAIN_WAVES + wave;
-    const bool live = t < P.n_tiles;               // wave-uniform; dead waves keep the ring protocol going
-    if (!live) t = P.n_tiles - 1;
-    const int64_t tbase = uniform64(t) * (K1 * NS * 512);   // element offset of this wave's tile inside a jet
-    constexpr int TILE_BYTES = K1 * NS * 1024;
-    const __amdgpu_buffer_rsrc_t a1r = jet_rsrc(P.A + tbase, TILE_BYTES);
-    bf8 bj[K1][NS];
-#pragma unroll
-    for (int c = 0; c < K1; ++c)
-#pragma unroll
-      for (int s = 0; s < NS; ++s)
-        bj[c][s] = ld_blk(a1r, lpos, (c * NS + s) * 1024);
-    CHAIN_STAMP(4);
-    for (int l = 1; l <= nh; ++l) {
-      f4 acc[K1][NTW];
-      zero_tiles<NTW, K1>(acc);
-      // a_l (= bj, this GEMM's B operand) goes out during this GEMM, two blocks per step; a_1 came from memory
-      const bool st_cur = live && P.spill && l >= 2, st_prev = live && P.spill && l >= 3;
-      const __amdgpu_buffer_rsrc_t dst = jet_rsrc(P.A + (int64_t)(l - 1) * P.jet_stride + tbase, TILE_BYTES);
-      static_for<0, NTW>([&](auto mt_) {
-        constexpr int MT = decltype(mt_)::value;
-        CHAIN_STAMP(2);
-        {
-          constexpr int QD = SLAB / 4 / 1024;
-          constexpr int E11 = chain_younger_stores<K1, NS, NTW, R, MT, true, true>();
-          constexpr int E10 = chain_younger_stores<K1, NS, NTW, R, MT, true, false>();
-          static_assert((R - 2) * QD + E11 <= 63, "vmcnt range");
-          if (l == 1 && MT < R - 1) ring.template wait_landed<K1 * NS>(g, burst);   // (a_L's burst of the previous tile batch)
-          else if (st_cur && st_prev) ring.template wait_landed<E11>(g, true);
-          else if (st_cur) ring.template wait_landed<E10>(g, true);
-          else ring.template wait_landed<0>(g, false);
-        }
-        CHAIN_STAMP(0);
-        __builtin_amdgcn_s_barrier();              // every quarter landed; every wave is done with slab g - 1
-        CHAIN_STAMP(1);
-        ring.issue();                              // ... whose ring slot is refilled now
-        if (st_cur) {
-#pragma unroll
-          for (int i = 0; i < chain_stores_at<K1, NS>(MT); ++i) {
-            const int idx = 2 * MT + i;
-            st_blk(dst, lpos, idx * 1024, bj[idx / NS][idx % NS]);
-          }
-        }
-        const char* sl = ring.consume_ptr();
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-          const bf8 ahi = *reinterpret_cast<const bf8*>(sl + s * 1024);
-          const bf8 alo = *reinterpret_cast<const bf8*>(sl + (NS + s) * 1024);
-#pragma unroll
-          for (int c = 0; c < K1; ++c) {
-            acc[c][MT] = mfma32(ahi, bj[c][s], acc[c][MT]);
-            acc[c][MT] = mfma32(alo, bj[c][s], acc[c][MT]);
-          }
-        }
-        ring.consumed();
-        ++g;
-      });
-      // activation (dnn.py:36-37): a = tanh(z + b), adot_j = (1 - a^2) zdot_j; packed straight into the next
-      // layer's B operand.  Only a_L is written here (no GEMM follows it in this kernel).
-      CHAIN_STAMP(2);
-      const float* bl = bias_lds + l * (16 * NTW);
-      const __amdgpu_buffer_rsrc_t dstL = jet_rsrc(P.A + (int64_t)l * P.jet_stride + tbase, TILE_BYTES);
-      burst = live && l == nh;
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        float o[K1][8];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const f4 b4 = *reinterpret_cast<const f4*>(bl + 16 * (2 * s + h) + 4 * q);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float a = tanh_bf(acc[0][2 * s + h][r] + b4[r]);
-            const float sv = fmaf(-a, a, 1.f);
-            o[0][4 * h + r] = a;
-#pragma unroll
-            for (int c = 1; c < K1; ++c) o[c][4 * h + r] = acc[c][2 * s + h][r] * sv;
-          }
-        }
-#pragma unroll
-        for (int c = 0; c < K1; ++c) {
-          bf8 v;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = (__bf16)o[c][j];
-          bj[c][s] = v;
-          if (burst) st_blk(dstL, lpos, (c * NS + s) * 1024, v);
-        }
-      }
-      CHAIN_STAMP(3);
-    }
-  }
-  wait_vm<0>();
-  CHAIN_DIAG_END(P);
-}
-
-
 // ============================================================================================================
 // Two waves per SIMD ("p8" kernels).  tools/ubench_ldsdma.hip: with ONE wave per SIMD a GEMM step of the chain
 // (64 MFMAs = 1024 matrix-pipe cycles) takes ~1800 cycles — bringing the 16 KB weight slab into LDS blocks the
@@ -464,11 +343,7 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_fwd8(const ChainParams 
   constexpr int NST = NG * NS;                   // stores per wave and layer
   static_assert(NST <= 2 * NTW && NST % 2 == 0, "two stores per step");
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#ifdef PINN_P8_ALL_EARLY
-  const bool early = true;
-#else
   const bool early = wave < 4;
-#endif
   const int q = lane >> 4, col = lane & 15, par = col >> 3, p8 = col & 7, half = wave & 1;
   // byte offset of this lane inside the tile's jet: row 8 half + p8 of the block of quantity `par` (+ 2G per group)
   const unsigned lvo = (unsigned)par * (NS * 1024) + (4u * (8u * half + p8) + q) * 16u;
@@ -483,9 +358,6 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_fwd8(const ChainParams 
   for (int i = threadIdx.x; i < (P.L + 1) * 16 * NTW; i += P8_THREADS) bias_lds[i] = P.bias[i];
   __syncthreads();
   p8_stagger();
-#ifdef PINN_P8_PRIO_LATE
-  if (!early) __builtin_amdgcn_s_setprio(1);
-#endif
   // The ring.  A wave's vector-memory operations retire in issue order, so "slab g has landed" is a vmcnt wait for
   // at most the operations issued after its copies.  To make that number a compile-time constant of the step, every
   // step issues the same operations whatever the layer: QD copies (past the last slab: of slab 0 into a spare slot
@@ -575,9 +447,7 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_fwd8(const ChainParams 
       };
       auto side = [&](auto m_) {      // this step's copies and its share of the a_l stores
         constexpr int M = decltype(m_)::value;
-#ifndef PINN_P8_EXP_NODMA
         issue();
-#endif
         if constexpr (2 * M < NST) {
 #pragma unroll
           for (int i = 2 * M; i < 2 * M + 2; ++i)
@@ -599,9 +469,7 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_fwd8(const ChainParams 
           } else wait_vm<N>();
         }
         CHAIN_STAMP(0);
-#ifndef PINN_P8_EXP_NOBAR
         __builtin_amdgcn_s_barrier();
-#endif
         CHAIN_STAMP(1);
         if (early) {
           side(mt_);
@@ -615,12 +483,8 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_fwd8(const ChainParams 
         const char* sl = ring.consume_ptr();
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-#ifdef PINN_P8_EXP_NOLDS
-          const bf8 ahi = bj[0][s], alo = bj[NG - 1][s];
-#else
           const bf8 ahi = *reinterpret_cast<const bf8*>(sl + s * 1024);
           const bf8 alo = *reinterpret_cast<const bf8*>(sl + (NS + s) * 1024);
-#endif
 #pragma unroll
           for (int G = 0; G < NG; ++G) {
             accc[G] = mfma32(ahi, bj[G][s], accc[G]);
@@ -854,273 +718,6 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_bwd(const ChainParam
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Reverse chain with eight waves (see k_chain_fwd8 for the layout and the step roles).  Per hidden matrix l = nh .. 1
-// the GEMM abar_l = W_l^T zbar_l runs on B = zbar_l (`bj`); output tile M of abar_l is final after step M and goes
-// through the activation adjoint with tile M of a_l at once, giving tile M of zbar_{l-1} (`bn`, the next GEMM's
-// operand; for l = 1: abar_1 itself, the kernel's output).  a_l arrives in k-step pieces (two output tiles) by LDS-DMA
-// into a four-slot staging area, four steps ahead of its use; the two waves of a tile copy half of the tile's blocks
-// each.  zbar_l goes out from `bj` during its own GEMM (weight-gradient operand).
-constexpr int CHAIN_RING8 = 5;             // weight slabs in the LDS ring of k_chain_bwd8 (beside 4 staging slots)
-constexpr int B8_STAGES = 4;
-
-// vector-memory operations one wave issues at GEMM step `step` of the reverse chain (any layer; negative steps are the
-// previous layer's): QD slab copies, then NG staging copies (even steps), then two zbar stores (first half).
-template <int QD, int NG, int NST, int NTW>
-__host__ __device__ constexpr int b8_stores_at(int step) { const int m = ((step % NTW) + NTW) % NTW; return 2 * m < NST ? 2 : 0; }
-template <int QD, int NG, int NST, int NTW>
-__host__ __device__ constexpr int b8_ops_at(int step) {
-  const int m = ((step % NTW) + NTW) % NTW;
-  return QD + ((m & 1) ? 0 : NG) + b8_stores_at<QD, NG, NST, NTW>(step);
-}
-template <int QD, int NG, int NST, int NTW>
-__host__ __device__ constexpr int b8_ops_in(int m0, int m1) { int n = 0; for (int m = m0; m < m1; ++m) n += b8_ops_at<QD, NG, NST, NTW>(m); return n; }
-// operations younger than the slab copies issued at step MT - (R - 1) / than the staging copies issued at step MT - 4
-template <int QD, int NG, int NST, int NTW, int R>
-__host__ __device__ constexpr int b8_younger_slab(int MT) {
-  return b8_ops_at<QD, NG, NST, NTW>(MT - (R - 1)) - QD + b8_ops_in<QD, NG, NST, NTW>(MT - (R - 2), MT);
-}
-template <int QD, int NG, int NST, int NTW>
-__host__ __device__ constexpr int b8_younger_stage(int MT) {
-  return b8_stores_at<QD, NG, NST, NTW>(MT - 4) + b8_ops_in<QD, NG, NST, NTW>(MT - 3, MT);
-}
-
-// Activation adjoint of one unit of one point.  The lane holds quantity 2G + par of group G: ab = abar, at = the jet of
-// a (at[0] on the par-0 lanes is the value a itself).  zbar_c = abar_c (1 - a^2) for the tangents;
-// zbar_0 = (1 - a^2) abar_0 - 2 a sum_c abar_c a_c   (tanh'' = -2 a (1 - a^2), fused_kernel.h activate_adjoint).
-template <int NG>
-__device__ __forceinline__ void p8_adjoint(const f2 (&ab)[NG], const f2 (&at)[NG], float parf, f2 (&out)[NG]) {
-  const f2 a = dpp2_hi_from_lo(at[0]);
-  const f2 sv = 1.f - a * a;
-  f2 part = (ab[0] * at[0]) * parf;
-#pragma unroll
-  for (int G = 1; G < NG; ++G) part = ab[G] * at[G] + part;
-  const f2 cross = part + dpp2_ror8(part);
-  const f2 t = ab[0] * sv;
-  out[0] = ((-2.f * (1.f - parf)) * a) * cross + t;       // par 1: tangent 1, abar sv; par 0: the value's adjoint
-#pragma unroll
-  for (int G = 1; G < NG; ++G) out[G] = ab[G] * sv;
-}
-
-template <int NTW, int K1>
-__global__ __launch_bounds__(P8_THREADS, 2) void k_chain_bwd8(const ChainParams P) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NS = NTW / 2;
-  constexpr int NG = (K1 + 1) / 2;
-  constexpr bool LO = PINN_CHAIN_BWD_LO != 0;
-  constexpr int SLAB = NS * (LO ? 2 : 1) * 1024;     // the hi pieces are the first NS planes of a packed slab
-  constexpr int QD = SLAB / P8_WAVES / 1024;
-  static_assert(QD >= 1 && QD * P8_WAVES * 1024 == SLAB, "slab split over 8 waves");
-  constexpr int R = CHAIN_RING8;
-  constexpr int NST = NG * NS;
-  static_assert(NST % 2 == 0 && NST <= 2 * NTW && NS % 2 == 0, "store / prologue schedule");
-  constexpr int TILE_STAGE = 2 * NG * 1024;          // per tile and piece: one block per quantity (odd K1: one spare)
-  constexpr int STAGE_BYTES = CHAIN_WAVES * TILE_STAGE;
-  constexpr int TILE_BYTES = K1 * NS * 1024;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const bool early = wave < 4;
-  const int q = lane >> 4, col = lane & 15, par = col >> 3, p8 = col & 7, half = wave & 1;
-  const unsigned lrow = (4u * (8u * half + p8) + q) * 16u;
-  const unsigned lvo = (unsigned)par * (NS * 1024) + lrow;
-  const unsigned lvo_last = ((K1 & 1) && par) ? 0x40000000u : lvo;
-  const float parf = (float)par;
-  const float live_col = ((K1 & 1) && par) ? 0.f : 1.f;   // last group, odd K1: this lane's column carries no quantity
-  const int nh = P.L - 1;
-  const int64_t n_tb = (P.n_tiles + CHAIN_WAVES - 1) / CHAIN_WAVES;
-  const int64_t my_tb = (n_tb - blockIdx.x + gridDim.x - 1) / gridDim.x;
-  p8_stagger();
-  SlabRing<NTW, SLAB, R, true, P8_WAVES> ring;     // slab order: layers nh-1 .. 0 (descending), tiles 0 .. NTW-1
-  ring.init(P.WTf, P.w_plane, smem, nh, my_tb * nh * NTW, wave, lane);
-  const __amdgpu_buffer_rsrc_t nowhere = jet_rsrc(P.G1, 0);
-  auto issue = [&]() {                              // constant operation count per step (see k_chain_fwd8)
-    if (ring.issued < ring.total) ring.issue();
-    else {
-#pragma unroll
-      for (int i = 0; i < QD; ++i) st_blk(nowhere, lvo, 0, bf8{0, 0, 0, 0, 0, 0, 0, 0});
-    }
-  };
-  char* stage = smem + R * SLAB + (wave >> 1) * TILE_STAGE;       // this wave's tile inside a staging slot
-  // piece s of the jet at a_tile: this wave copies the blocks of quantities half * NG .. + NG - 1 of its tile
-  auto stage_piece = [&](const unsigned short* a_tile, int s, int slot) {
-#pragma unroll
-    for (int i = 0; i < NG; ++i) {
-      const int c = half * NG + i;
-      const int cs = c < K1 ? c : K1 - 1;           // (odd K1: the spare block gets a copy of the last quantity; never used)
-      dma_1k<PINN_CHAIN_JET_LD_AUX>(a_tile + (cs * NS + s) * 512, stage + slot * STAGE_BYTES + c * 1024, lane);
-    }
-  };
-  auto read_piece = [&](int slot, bf8 (&ap)[NG]) {
-#pragma unroll
-    for (int G = 0; G < NG; ++G)
-      ap[G] = *reinterpret_cast<const bf8*>(stage + slot * STAGE_BYTES + (2 * G + par) * 1024 + lrow);
-  };
-  for (int g0 = 0; g0 < R - 1; ++g0) issue();
-  CHAIN_DIAG_BEGIN;
-  bf8 bj[NG][NS], bn[NG][NS];
-#pragma unroll
-  for (int G = 0; G < NG; ++G)
-#pragma unroll
-    for (int s = 0; s < NS; ++s) bn[G][s] = bf8{0, 0, 0, 0, 0, 0, 0, 0};
-  int64_t prev_base = 0;
-  bool prev_live = false;
-  for (int64_t tb = blockIdx.x; tb < n_tb; tb += gridDim.x) {
-    int64_t t = tb * CHAIN_WAVES + (wave >> 1);
-    const bool live = t < P.n_tiles;
-    if (!live) t = P.n_tiles - 1;
-    const int64_t tbase = uniform64(t) * (K1 * NS * 512);
-    // ---- batch prologue: zbar_nh = adjoint(abar_L, a_L), both from memory, in two halves of the k-steps.  Order of
-    // the second half: loads, the staging copies of the first two pieces of a_nh, the stores of the PREVIOUS batch's
-    // abar_1 (still in `bn`), then the arithmetic — nothing a wait of this batch covers is younger than the stores.
-    {
-      const __amdgpu_buffer_rsrc_t glr = jet_rsrc(P.GL + tbase, TILE_BYTES);
-      const __amdgpu_buffer_rsrc_t alr = jet_rsrc(P.A + (int64_t)nh * P.jet_stride + tbase, TILE_BYTES);
-      const unsigned short* a_nh = P.A + (int64_t)(nh - 1) * P.jet_stride + tbase;
-      static_for<0, 2>([&](auto hh_) {
-        constexpr int S0 = decltype(hh_)::value * (NS / 2);
-        bf8 gv[NG][NS / 2], av[NG][NS / 2];
-#pragma unroll
-        for (int G = 0; G < NG; ++G)
-#pragma unroll
-          for (int s = 0; s < NS / 2; ++s) {
-            gv[G][s] = ld_blk(glr, G == NG - 1 ? lvo_last : lvo, (2 * G * NS + S0 + s) * 1024);
-            av[G][s] = ld_blk(alr, G == NG - 1 ? lvo_last : lvo, (2 * G * NS + S0 + s) * 1024);
-          }
-        if constexpr (S0 > 0) {
-          stage_piece(a_nh, 0, 0);
-          stage_piece(a_nh, 1, 1);
-          const __amdgpu_buffer_rsrc_t g1r = jet_rsrc(P.G1 + prev_base, prev_live ? TILE_BYTES : 0);
-#pragma unroll
-          for (int G = 0; G < NG; ++G)
-#pragma unroll
-            for (int s = 0; s < NS; ++s) st_blk(g1r, G == NG - 1 ? lvo_last : lvo, (2 * G * NS + s) * 1024, bn[G][s]);
-        }
-#pragma unroll
-        for (int s = 0; s < NS / 2; ++s)
-#pragma unroll
-          for (int j = 0; j < 8; j += 2) {
-            f2 ab[NG], at[NG], o[NG];
-#pragma unroll
-            for (int G = 0; G < NG; ++G) { ab[G] = bf2f2(gv[G][s], j); at[G] = bf2f2(av[G][s], j); }
-            p8_adjoint<NG>(ab, at, parf, o);
-#pragma unroll
-            for (int G = 0; G < NG; ++G) { bj[G][S0 + s][j] = (__bf16)o[G][0]; bj[G][S0 + s][j + 1] = (__bf16)o[G][1]; }
-          }
-      });
-    }
-    prev_base = tbase; prev_live = live;
-    CHAIN_STAMP(6);
-    for (int l = nh; l >= 1; --l) {
-      f4 accp[NG];
-      bf8 ap[2][NG];                                // pieces of a_l: even / odd piece numbers
-      const __amdgpu_buffer_rsrc_t zdst = jet_rsrc(P.Z + (int64_t)(l - 1) * P.jet_stride + tbase, live ? TILE_BYTES : 0);
-      const unsigned short* a_cur = P.A + (int64_t)(l - 1) * P.jet_stride + tbase;                  // a_l
-      const unsigned short* a_nxt = P.A + (int64_t)(l >= 2 ? l - 2 : 0) * P.jet_stride + tbase;     // a_{l-1} (l = 1: unused copies)
-      // adjoint of output tile M (l >= 2), or abar_1 as it is (l = 1)
-      auto act = [&](auto m_, const f4 (&a)[NG]) {
-        constexpr int M = decltype(m_)::value, s = M / 2, h = M % 2;
-#pragma unroll
-        for (int r = 0; r < 4; r += 2) {
-          f2 ab[NG], at[NG], o[NG];
-#pragma unroll
-          for (int G = 0; G < NG; ++G) { ab[G] = f2{a[G][r], a[G][r + 1]}; at[G] = bf2f2(ap[s & 1][G], 4 * h + r); }
-          if constexpr (K1 & 1) at[NG - 1] = at[NG - 1] * live_col;      // (the spare staging block holds a copy, not zeros)
-          if (l >= 2) p8_adjoint<NG>(ab, at, parf, o);
-          else {
-#pragma unroll
-            for (int G = 0; G < NG; ++G) o[G] = ab[G];
-          }
-#pragma unroll
-          for (int G = 0; G < NG; ++G) { bn[G][s][4 * h + r] = (__bf16)o[G][0]; bn[G][s][4 * h + r + 1] = (__bf16)o[G][1]; }
-        }
-      };
-      auto side = [&](auto m_) {
-        constexpr int M = decltype(m_)::value;
-        issue();
-        if constexpr ((M & 1) == 0) {
-          if constexpr (M + 4 < NTW) stage_piece(a_cur, (M + 4) / 2, ((M + 4) / 2) % B8_STAGES);
-          else stage_piece(a_nxt, (M + 4 - NTW) / 2, ((M + 4 - NTW) / 2) % B8_STAGES);
-        }
-        if constexpr (2 * M < NST) {
-#pragma unroll
-          for (int i = 2 * M; i < 2 * M + 2; ++i)
-            st_blk(zdst, i / NS == NG - 1 ? lvo_last : lvo, (2 * (i / NS) * NS + i % NS) * 1024, bj[i / NS][i % NS]);
-        }
-      };
-      static_for<0, NTW>([&](auto mt_) {
-        constexpr int MT = decltype(mt_)::value;
-        CHAIN_STAMP(5);
-        {
-          constexpr int NSL = b8_younger_slab<QD, NG, NST, NTW, R>(MT);
-          constexpr int NSG = b8_younger_stage<QD, NG, NST, NTW>(MT);
-          constexpr int N = (MT & 1) ? NSL : (NSG < NSL ? NSG : NSL);
-          // first layer of a batch, first four steps: the slabs were copied before the prologue, whose load waits
-          // retired them; the staging copies of pieces 0 and 1 and the stores sit in the prologue
-          constexpr int NF = MT == 0 ? NG + NST
-                           : MT == 2 ? NST + b8_ops_in<QD, NG, NST, NTW>(0, 2)
-                                     : 2 * NG + NST + b8_ops_in<QD, NG, NST, NTW>(0, MT);
-          static_assert(N <= 63 && (MT >= 4 || NF <= 63), "vmcnt range");
-          if (MT < 4 && l == nh) wait_vm<(MT < 4 ? NF : 0)>();
-          else wait_vm<N>();
-        }
-        CHAIN_STAMP(0);
-        __builtin_amdgcn_s_barrier();
-        CHAIN_STAMP(1);
-        if constexpr ((MT & 1) == 0) read_piece((MT / 2) % B8_STAGES, ap[(MT / 2) & 1]);
-        if (early) {
-          side(mt_);
-          CHAIN_STAMP(4);
-          if constexpr (MT > 0) act(std::integral_constant<int, (MT > 0 ? MT - 1 : 0)>{}, accp);
-          CHAIN_STAMP(3);
-        }
-        f4 accc[NG];
-#pragma unroll
-        for (int G = 0; G < NG; ++G) accc[G] = f4{0.f, 0.f, 0.f, 0.f};
-        const char* sl = ring.consume_ptr();
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-          const bf8 ahi = *reinterpret_cast<const bf8*>(sl + s * 1024);
-#pragma unroll
-          for (int G = 0; G < NG; ++G) accc[G] = mfma32(ahi, bj[G][s], accc[G]);
-          if constexpr (LO) {
-            const bf8 alo = *reinterpret_cast<const bf8*>(sl + (NS + s) * 1024);
-#pragma unroll
-            for (int G = 0; G < NG; ++G) accc[G] = mfma32(alo, bj[G][s], accc[G]);
-          }
-        }
-        ring.consumed();
-        CHAIN_STAMP(2);
-        if (!early) {
-          side(mt_);
-          CHAIN_STAMP(4);
-          act(mt_, accc);
-          CHAIN_STAMP(3);
-        }
-#pragma unroll
-        for (int G = 0; G < NG; ++G) accp[G] = accc[G];
-      });
-      CHAIN_STAMP(5);
-      if (early) act(std::integral_constant<int, NTW - 1>{}, accp);
-      CHAIN_STAMP(3);
-      if (l >= 2) {
-#pragma unroll
-        for (int G = 0; G < NG; ++G)
-#pragma unroll
-          for (int s = 0; s < NS; ++s) bj[G][s] = bn[G][s];
-      }
-      CHAIN_STAMP(5);
-    }
-  }
-  {   // abar_1 of the last batch
-    const __amdgpu_buffer_rsrc_t g1r = jet_rsrc(P.G1 + prev_base, prev_live ? TILE_BYTES : 0);
-#pragma unroll
-    for (int G = 0; G < NG; ++G)
-#pragma unroll
-      for (int s = 0; s < NS; ++s) st_blk(g1r, G == NG - 1 ? lvo_last : lvo, (2 * G * NS + s) * 1024, bn[G][s]);
-  }
-  wait_vm<0>();
-  CHAIN_DIAG_END8(P);
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // Weight gradient of all hidden matrices in one launch.  Workgroup b -> (layer li = b % nh, slice b / nh); wave w
 // owns output-unit tiles [w * MTB, (w + 1) * MTB) x all NTW input tiles of dW_l in registers.  The contraction
 // runs over (quantity c, point p): per tile two k-steps of 32 — k-step u holds quantities 2u, 2u + 1 (lane group
@@ -1136,116 +733,9 @@ __device__ __forceinline__ bf8 tr_operand(const char* p0) {   // two transposed 
   return __builtin_bit_cast(bf8, v);
 }
 
-template <int NTW, int K1>
-__global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_wgrad(const ChainParams P) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NS = NTW / 2;
-  constexpr int MTB = NTW / CHAIN_WAVES;           // output tiles per wave: 4 (W = 256) or 2 (W = 128)
-  constexpr int KU = (K1 + 1) / 2;                 // k-steps per tile
-  constexpr int HALF = 2 * NS * 1024;              // bytes of one operand's two quantities
-  constexpr int UNIT = 2 * HALF;                   // [zbar c0 | zbar c1 | a c0 | a c1] x NS blocks
-  constexpr int UDMA = UNIT / 1024 / CHAIN_WAVES;  // 1 KB copies per wave and unit
-  constexpr int RU = WG_UNITS;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i16 = lane & 15, qk = lane >> 4;
-  const int nh = P.L - 1;
-  const int li = blockIdx.x % nh, slice = blockIdx.x / nh;
-  if (slice >= P.n_slices) return;                 // (workgroup-uniform)
-  const int64_t t0 = P.n_tiles * slice / P.n_slices, t1 = P.n_tiles * (slice + 1) / P.n_slices;
-  const int64_t U = (t1 - t0) * KU;                // ring units this workgroup consumes
-  const unsigned short* Zl = P.Z + (int64_t)li * P.jet_stride;        // zbar_{li+1}
-  const unsigned short* Al = P.A + (int64_t)li * P.jet_stride;        // a_{li+1} (the layer's input)
-  auto issue_unit = [&](int64_t u) {
-    if (u >= U) return;
-    const int64_t t = t0 + u / KU;
-    const int ku = (int)(u % KU);
-    char* dst = smem + (int)(u % RU) * UNIT;
-    // copy j of this wave: j' = wave * UDMA + j in [0, 4 NS): operand (j' / (2 NS)), quantity 2 ku + (j' / NS) % 2, block j' % NS
-#pragma unroll
-    for (int j = 0; j < UDMA; ++j) {
-      const int jj = wave * UDMA + j;
-      const int op = jj / (2 * NS), cq = (jj / NS) & 1, s = jj % NS;
-      int c = 2 * ku + cq;
-      if (c >= K1) c = K1 - 1;                     // odd K1: the missing quantity is masked at the MFMA operand
-      const unsigned short* src = (op ? Al : Zl) + ((t * K1 + c) * NS + s) * 512;
-      dma_1k<PINN_CHAIN_JET_LD_AUX>(src, dst + jj * 1024, lane);
-    }
-  };
-  f4 dw[MTB][NTW];
-  float bs[MTB];
-#pragma unroll
-  for (int m = 0; m < MTB; ++m) {
-    bs[m] = 0.f;
-#pragma unroll
-    for (int n = 0; n < NTW; ++n) dw[m][n] = f4{0.f, 0.f, 0.f, 0.f};
-  }
-  for (int u0 = 0; u0 < RU - 1; ++u0) issue_unit(u0);
-  // address of this lane's transposed-read element inside a quantity's NS-block region:
-  // rows = points 8 (qk & 1) + (i16 >> 2) (+4 for the second read), column quad = i16 & 3, at fixed (s, h)
-  const int tr_lane = (8 * (qk & 1) + (i16 >> 2)) * 64 + (i16 & 3) * 16;
-  const int cq_lane = qk >> 1;                     // which of the unit's two quantities this lane group contracts
-  CHAIN_DIAG_BEGIN;
-  for (int64_t u = 0; u < U; ++u) {
-    CHAIN_STAMP(2);
-    if (u + RU - 1 > U) wait_vm<0>();              // fewer than RU - 2 younger units exist: drain
-    else wait_vm<(RU - 2) * UDMA>();
-    CHAIN_STAMP(0);
-    __builtin_amdgcn_s_barrier();
-    CHAIN_STAMP(1);
-    issue_unit(u + RU - 1);
-    const char* ub = smem + (int)(u % RU) * UNIT;
-    const int ku = (int)(u % KU);
-    const bool qlive = 2 * ku + cq_lane < K1;      // odd K1: the padded quantity contributes nothing
-    const char* zb = ub + cq_lane * (NS * 1024) + tr_lane;
-    const char* ab = ub + HALF + cq_lane * (NS * 1024) + tr_lane;
-    bf8 za[MTB];
-#pragma unroll
-    for (int m = 0; m < MTB; ++m) {
-      const int MT = wave * MTB + m;
-      bf8 v = tr_operand(zb + (MT >> 1) * 1024 + (MT & 1) * 8);
-      if (!qlive) v = bf8{0, 0, 0, 0, 0, 0, 0, 0};
-      za[m] = v;
-      if (ku == 0 && qk < 2) {                     // bias gradient: sum over points of zbar's value quantity
-        float sacc = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sacc += bf2f(v[j]);
-        bs[m] += sacc;
-      }
-    }
-#pragma unroll
-    for (int n = 0; n < NTW; ++n) {
-      const bf8 bb = tr_operand(ab + (n >> 1) * 1024 + (n & 1) * 8);
-#pragma unroll
-      for (int m = 0; m < MTB; ++m) dw[m][n] = mfma32(za[m], bb, dw[m][n]);
-    }
-  }
-  wait_vm<0>();
-  CHAIN_STAMP(2);
-  CHAIN_DIAG_END(P);
-  // one flush per wave into the flat torch-layout gradient: dW_l (out, in) row-major, then b_l
-  float* dWl = P.dW + P.w_off1 + (int64_t)li * P.w_per;
-  float* dbl = dWl + (int64_t)P.W * P.W;
-#pragma unroll
-  for (int m = 0; m < MTB; ++m) {
-    const int MT = wave * MTB + m;
-#pragma unroll
-    for (int n = 0; n < NTW; ++n)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * MT + 4 * qk + r, col = 16 * n + i16;
-        if (row < P.W && col < P.W)
-          __hip_atomic_fetch_add(dWl + (int64_t)row * P.W + col, dw[m][n][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    float tsum = bs[m];                            // lanes (i16, qk = 0, 1) hold points 0-7 / 8-15 of unit 16 MT + i16
-    tsum += __shfl_xor(tsum, 16, 64);
-    const int row = 16 * MT + i16;
-    if (qk == 0 && row < P.W) __hip_atomic_fetch_add(dbl + row, tsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// The same with eight waves, two per SIMD (see k_chain_fwd8): the kernel streams 2 x 2 GB of jets per layer and its
-// unit time was set by the 8 copies per wave that open a unit — a wave alone on its SIMD issues nothing else
-// while a copy is being accepted — not by its 64 MFMAs.  Each of eight waves issues 4 copies and owns half the rows.
+// Eight waves, two per SIMD with the step roles of k_chain_fwd8: the kernel streams 2 x 2 GB of jets per layer, and
+// with four waves its unit time was set by the 8 copies per wave that open a unit — a wave alone on its SIMD issues
+// nothing else while a copy is being accepted — not by its 64 MFMAs (10.5 ms at 12 x 256 / 2^20 points; 8.5 ms so).
 template <int NTW, int K1>
 __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_wgrad8(const ChainParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1356,11 +846,8 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_wgrad8(const ChainParam
   }
 }
 
-template <int NTW> int launch_chain_fwd(int K1, const ChainParams& P, int grid, hipStream_t s);
 template <int NTW> int launch_chain_fwd8(int K1, const ChainParams& P, int grid, hipStream_t s);
 template <int NTW> int launch_chain_bwd(int K1, const ChainParams& P, int grid, hipStream_t s);
-template <int NTW> int launch_chain_bwd8(int K1, const ChainParams& P, int grid, hipStream_t s);
-template <int NTW> int launch_chain_wgrad(int K1, const ChainParams& P, int grid, hipStream_t s);
 template <int NTW> int launch_chain_wgrad8(int K1, const ChainParams& P, int grid, hipStream_t s);
 
 }  // namespace pinn

@@ -223,12 +223,6 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
     if (hipMemsetAsync(P.wg_sums + (int64_t)Lp.sums_slot * MAX_SUMS, 0, (size_t)w.grid * MAX_SUMS * 4, s) != hipSuccess) {
       set_error("hipMemsetAsync failed"); return PINN_ERR_LAUNCH;
     }
-#ifndef PINN_THIN_MULT
-#define PINN_THIN_MULT 1
-#endif
-    // bf16 mode's first / last layer kernels stream 2 GB of jets each and are latency-bound at one workgroup per CU:
-    // workgroups per CU where their register use allows it
-    constexpr int THIN_WGRAD_LAST_WGS = PINN_THIN_MULT > 1 ? 4 : 1, THIN_BWD_FIRST_WGS = PINN_THIN_MULT > 1 ? 2 : 1, THIN_WGRAD_FIRST_WGS = PINN_THIN_MULT > 1 ? 2 : 1;
     if (chain) {
       // ---- bf16 mode: first / last layer on this file's kernels (fp32 MFMA on the thin matrices, chain-layout
       // bf16 jets), the L - 1 hidden matrices on the three chain kernels (chain_kernel.h) ----
@@ -251,11 +245,7 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
 #ifdef PINN_CHAIN_DIAG
       C.diag = dbuf;
 #endif
-#ifdef PINN_CHAIN_FWD4
-      if (nh > 0) { rc = launch_chain_fwd<NTW>(K1, C, cgrid, s); if (rc) break; }
-#else
       if (nh > 0) { rc = launch_chain_fwd8<NTW>(K1, C, cgrid, s); if (rc) break; }
-#endif
       Lp.W = Wp + woff(L); Lp.b = Bp + L * g.WP; Lp.in_act = jetA(L); Lp.out_act = nullptr; Lp.g_out = gout;
       rc = launch_wide_fwd<NTW>(2, K1, prec, grad, P, Lp, grid, s); if (rc) break;
 #ifdef PINN_CHAIN_DIAG
@@ -272,45 +262,33 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
       // output layer: dW_L = G . a_L^T ; abar_L = W_L^T G (bf16, chain layout)
       Lp.g_in = gout; Lp.in_act = jetA(L); Lp.in_d = n.in_dim(L); Lp.out_d = n.out_dim(L);
       Lp.dW = rq->grad + n.w_off(L); Lp.db = rq->grad + n.b_off(L);
-      rc = launch_wide_wgrad<NTW>(2, K1, prec, P, Lp, w.grid * THIN_WGRAD_LAST_WGS, s); if (rc) break;
+      rc = launch_wide_wgrad<NTW>(2, K1, prec, P, Lp, w.grid, s); if (rc) break;
       Lp.W = WTp + woff(L); Lp.g_out = (float*)C.GL;
       rc = launch_wide_bwd<NTW>(2, K1, prec, P, Lp, grid, s); if (rc) break;
 #ifdef PINN_CHAIN_DIAG
       C.diag = dbuf + 8;
 #endif
-#ifdef PINN_CHAIN_BWD4
       if (nh > 0) { rc = launch_chain_bwd<NTW>(K1, C, cgrid, s); if (rc) break; }
-#else
-      if (nh > 0) { rc = launch_chain_bwd8<NTW>(K1, C, cgrid, s); if (rc) break; }
-#endif
       // first layer: zbar_0 = adjoint(abar_1, a_1), in place over abar_1; dW_0 = zbar_0 . (x, e_j)^T
       Lp.g_in = (float*)C.G1; Lp.in_act = jetA(1); Lp.g_out = nullptr; Lp.W = nullptr; Lp.z_out = (float*)C.G1;
-      {
-        const int64_t wgs = (Lp.n_tiles + WIDE_WAVES - 1) / WIDE_WAVES;
-        const int g2 = (int)(wgs < (int64_t)w.grid * THIN_BWD_FIRST_WGS ? wgs : (int64_t)w.grid * THIN_BWD_FIRST_WGS);
-        rc = launch_wide_bwd<NTW>(0, K1, prec, P, Lp, g2, s); if (rc) break;
-      }
+      rc = launch_wide_bwd<NTW>(0, K1, prec, P, Lp, grid, s); if (rc) break;
       Lp.g_in = (float*)C.G1; Lp.in_act = nullptr; Lp.in_d = n.in_dim(0); Lp.out_d = n.out_dim(0);
       Lp.dW = rq->grad + n.w_off(0); Lp.db = rq->grad + n.b_off(0);
-      rc = launch_wide_wgrad<NTW>(0, K1, prec, P, Lp, w.grid * THIN_WGRAD_FIRST_WGS, s); if (rc) break;
+      rc = launch_wide_wgrad<NTW>(0, K1, prec, P, Lp, w.grid, s); if (rc) break;
       if (nh > 0) {
         C.n_slices = w.grid / nh > 0 ? w.grid / nh : 1;
         if ((int64_t)C.n_slices > Lp.n_tiles) C.n_slices = (int)Lp.n_tiles;
 #ifdef PINN_CHAIN_DIAG
         C.diag = dbuf + 16;
 #endif
-#ifdef PINN_CHAIN_WGRAD4
-        rc = launch_chain_wgrad<NTW>(K1, C, C.n_slices * nh, s); if (rc) break;
-#else
         rc = launch_chain_wgrad8<NTW>(K1, C, C.n_slices * nh, s); if (rc) break;
-#endif
 #ifdef PINN_CHAIN_DIAG
         {
           unsigned long long h[48];
           (void)hipStreamSynchronize(s);
           (void)hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost);
-          for (int k8 = 0; k8 < 4; ++k8) {
-            const unsigned long long* d = h + (k8 == 0 ? 0 : k8 == 1 ? 24 : k8 == 2 ? 8 : 32);
+          for (int k8 = 0; k8 < 2; ++k8) {
+            const unsigned long long* d = h + (k8 == 0 ? 0 : 24);
             unsigned long long tot = 0; for (int i = 0; i < 8; ++i) tot += d[i];
             fprintf(stderr, "CHAIN_DIAG %s %s wave: wait %.1f%% barrier %.1f%% reads+mfma %.1f%% act %.1f%% copies+stores %.1f%% other %.1f%% tile-io %.1f%% | total %llu cycles\n",
                     k8 < 2 ? "fwd8" : "bwd8", (k8 & 1) ? "late" : "early", 100.0 * d[0] / tot, 100.0 * d[1] / tot, 100.0 * d[2] / tot, 100.0 * d[3] / tot, 100.0 * d[4] / tot, 100.0 * d[5] / tot, 100.0 * d[6] / tot, tot);
