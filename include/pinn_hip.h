@@ -20,6 +20,7 @@
  *   pinn_residual_mse_split_loss_grad  train.py:131-157 (fidelity set + collocation set, one launch)
  *   pinn_lbfgs_push / pinn_lbfgs_direction  torch.optim.LBFGS's two-loop recursion (train.py:116-125,200)
  *   pinn_adam_step          torch.optim.Adam.step as called at train.py:192
+ *   pinn_loss_grad_adam_step  train.py:189-193 (loss_func + backward + Adam.step) in two launches
  *
  * Conventions
  *   - plain C, no exceptions; every function returns 0 on success, <0 on error;
@@ -45,7 +46,7 @@
 extern "C" {
 #endif
 
-#define PINN_ABI_VERSION 2
+#define PINN_ABI_VERSION 3
 
 #define PINN_MAX_DIRS 3   /* tangent directions (inputs with requires_grad) */
 #define PINN_MAX_ROLES 8
@@ -188,6 +189,33 @@ int32_t pinn_residual_mse_split_loss_grad(const pinn_desc* desc, const pinn_resi
                                           const float* params, const float* X, int64_t N, int64_t n_res,
                                           float* term_sums, float* col_sums, float* grad_flat,
                                           void* ws, int64_t ws_bytes, void* stream);
+
+/* train.py:189-193 as TWO launches (fused engine, one-pass requests): loss_func's forward + residual + backward, then
+ * ONE kernel that finishes the loss sums and the gradient, applies torch.optim.Adam's update (pinn_adam_step's
+ * arithmetic, bit for bit) to params / m / v and refreshes the packed weights in `ws` that the next call's first
+ * kernel reads.  At the reference's own problem sizes (N_res = 243, config_CMB.json:43) the iteration is bound by
+ * its launches: pack + pass + two reductions + zero-fill + update were six of them.
+ *   X, n_res: as pinn_residual_mse_split_loss_grad (n_res == N: residual term only, n_cols may be 0;
+ *             n_res < 0: both terms on every point, train_newmethod.py:122-159).
+ *   grad_flat is OVERWRITTEN with this iteration's gradient (no zero-fill needed).
+ *   adam->packed_valid: nonzero iff the previous call on this `ws` was this function with the same desc and
+ *             nothing has written params since — the call then skips the packing kernel.
+ * Returns PINN_ERR_UNSUPPORTED, having launched nothing, when the request would not run as one pass of the fused
+ * engine (wide / generic engines, large split requests): use the loss call followed by pinn_adam_step. */
+typedef struct pinn_adam_state {
+  float* m;              /* exp_avg    (P) */
+  float* v;              /* exp_avg_sq (P) */
+  int64_t step;          /* 1-based, as torch counts */
+  double lr, beta1, beta2, eps;
+  int32_t packed_valid;
+  int32_t reserved;
+} pinn_adam_state;
+int32_t pinn_loss_grad_adam_step(const pinn_desc* desc, const pinn_residual_spec* spec,
+                                 const float* term_scale, const float* T, int32_t n_cols,
+                                 const int32_t* out_col, const float* col_scale,
+                                 float* params, const float* X, int64_t N, int64_t n_res,
+                                 float* term_sums, float* col_sums, float* grad_flat,
+                                 const pinn_adam_state* adam, void* ws, int64_t ws_bytes, void* stream);
 
 /* torch.optim.Adam single-tensor update on flat buffers (amsgrad off, weight_decay 0,
  * maximize off): m,v are exp_avg / exp_avg_sq; step is the 1-based step count;

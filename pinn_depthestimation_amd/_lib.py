@@ -16,7 +16,7 @@ PINN_MAX_ROLES = 8
 ACT_TANH, ACT_LEAKY_RELU = 0, 1
 ENGINE_AUTO, ENGINE_GENERIC, ENGINE_FUSED, ENGINE_WIDE = 0, 1, 2, 3
 ENGINE_FUSED_TILE, ENGINE_FUSED_COOP = 4, 5     # sub-values of ENGINE_FUSED: force one of its kernels (pinn_hip.h)
-ABI_VERSION = 2
+ABI_VERSION = 3
 PREC_F32, PREC_BF16 = 0, 1
 
 RES_NAVIER_STOKES, RES_PHYSICS_EQUATION, RES_CONTINUITY_FTEMP, RES_CONTINUITY_ONLY = 1, 2, 3, 4
@@ -37,6 +37,16 @@ class PinnResidualSpec(C.Structure):
         ("residual_id", C.c_int32), ("out_col", C.c_int32 * PINN_MAX_ROLES),
         ("dir_of", C.c_int32 * PINN_MAX_DIRS), ("flags", C.c_int32), ("param", C.c_float * 4),
     ]
+
+
+class PinnAdamState(C.Structure):
+    _fields_ = [
+        ("m", C.c_void_p), ("v", C.c_void_p), ("step", C.c_int64), ("lr", C.c_double), ("beta1", C.c_double),
+        ("beta2", C.c_double), ("eps", C.c_double), ("packed_valid", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+ERR_UNSUPPORTED = -2
 
 
 class PinnError(RuntimeError):
@@ -74,6 +84,9 @@ _SIGNATURES = {
                                             C.c_int64, _P]),
     "pinn_adam_step": (C.c_int32, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double,
                                    C.c_double, _P]),
+    "pinn_loss_grad_adam_step": (C.c_int32, [C.POINTER(PinnDesc), C.POINTER(PinnResidualSpec), _P, _P, C.c_int32,
+                                             C.POINTER(C.c_int32), _P, _P, _P, C.c_int64, C.c_int64, _P, _P, _P,
+                                             C.POINTER(PinnAdamState), _P, C.c_int64, _P]),
 }
 
 _lib = None

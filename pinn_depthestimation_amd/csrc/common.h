@@ -56,6 +56,14 @@ __host__ __device__ inline uint32_t dropout_threshold(float p) {
 }
 
 // what a loss call asks the engines for
+// torch.optim.Adam's update folded into the kernel that finishes a loss + gradient pass (pinn_loss_grad_adam_step)
+struct AdamReq {
+  float* params;        // updated in place (the pass itself read the PACKED copy of them in the workspace)
+  float* m; float* v;
+  float w1, b2, w2, eps, step_size, bc2_sqrt;   // as pinn_adam_step forms them
+  bool packed_valid;    // the workspace's packed weights already equal params (left there by the previous call)
+};
+
 struct LossReq {
   int kind;  // 0 = residual, 1 = mse, 2 = residual + mse in one pass
   int64_t n_split;  // kind 2: < 0 both terms on every point; >= 0 residual on points [0, n_split), mse on [n_split, N)
@@ -68,6 +76,7 @@ struct LossReq {
   const float* mse_scale;   // device col_scale
   float* mse_sums;          // device col_sums
   float* grad;          // device flat grad (+=) or null
+  const AdamReq* adam;  // fused engine only: grad is OVERWRITTEN with this pass's gradient and the update applied
 };
 
 // generic engine (pinn_generic.hip)
@@ -81,6 +90,7 @@ int generic_loss(const Net& n, const LossReq& rq, const float* params, const flo
 
 // fused MFMA engine (pinn_fused.hip)
 bool fused_supports(const Net& n, bool want_grad);
+bool fused_supports_adam(const Net& n, const LossReq& rq, int64_t N);   // one-pass requests only
 int64_t fused_workspace_bytes(const Net& n, int64_t N);
 int fused_forward(const Net& n, const float* params, const float* X, int64_t N, float* Y, float* dY,
                   void* ws, int64_t ws_bytes, hipStream_t s);

@@ -363,4 +363,45 @@ int32_t pinn_adam_step(float* params, const float* grad, float* m, float* v, int
   return check_launch("adam");
 }
 
+int32_t pinn_loss_grad_adam_step(const pinn_desc* desc, const pinn_residual_spec* spec, const float* term_scale,
+                                 const float* T, int32_t n_cols, const int32_t* out_col, const float* col_scale,
+                                 float* params, const float* X, int64_t N, int64_t n_res, float* term_sums,
+                                 float* col_sums, float* grad_flat, const pinn_adam_state* adam, void* ws,
+                                 int64_t ws_bytes, void* stream) {
+  Net n; int rc = make_net(desc, &n); if (rc) return rc;
+  if (!spec || !adam) { set_error("NULL pointer argument"); return PINN_ERR_INVALID; }
+  rc = check_spec(n, spec); if (rc) return rc;
+  if (!params || !X || N < 1 || !term_sums || !term_scale || !grad_flat || !adam->m || !adam->v || adam->step < 1) {
+    set_error("bad arguments"); return PINN_ERR_INVALID;
+  }
+  if (n_res > N) { set_error("n_res=%lld exceeds N=%lld", (long long)n_res, (long long)N); return PINN_ERR_INVALID; }
+  if (n_cols < 0 || n_cols > PINN_MAX_ROLES) { set_error("n_cols=%d outside 0..%d", n_cols, PINN_MAX_ROLES); return PINN_ERR_INVALID; }
+  if (n_cols == 0 && n_res != N) { set_error("no fidelity columns: n_res must equal N"); return PINN_ERR_INVALID; }
+  if (n_cols > 0 && (!out_col || !col_scale || !col_sums || (!T && n_res != N))) { set_error("NULL pointer argument"); return PINN_ERR_INVALID; }
+  LossReq rq; memset(&rq, 0, sizeof(rq));
+  rq.spec = *spec; rq.scale = term_scale; rq.sums = term_sums; rq.n_terms = residual_terms(spec->residual_id);
+  rq.T = T; rq.n_cols = n_cols; rq.mse_scale = col_scale; rq.mse_sums = col_sums; rq.grad = grad_flat;
+  for (int j = 0; j < n_cols; ++j) {
+    if (out_col[j] < 0 || out_col[j] >= n.d_out) { set_error("out_col[%d]=%d out of range", j, out_col[j]); return PINN_ERR_INVALID; }
+    rq.out_col[j] = out_col[j];
+  }
+  if (n_res == N) { rq.kind = 0; rq.n_split = -1; }      // residual term only
+  else { rq.kind = 2; rq.n_split = n_res < 0 ? -1 : n_res; }
+  const int e = pick_engine(desc, n, true, &rc); if (rc) return rc;
+  if (e != PINN_ENGINE_FUSED || !fused_supports_adam(n, rq, N)) {
+    set_error("pinn_loss_grad_adam_step: needs a one-pass request on the fused engine (use the loss call + pinn_adam_step)");
+    return PINN_ERR_UNSUPPORTED;
+  }
+  AdamReq a;
+  const double bc1 = 1.0 - pow(adam->beta1, (double)adam->step);
+  const double bc2 = 1.0 - pow(adam->beta2, (double)adam->step);
+  a.params = params; a.m = adam->m; a.v = adam->v;
+  a.w1 = (float)(1.0 - adam->beta1); a.b2 = (float)adam->beta2; a.w2 = (float)(1.0 - adam->beta2); a.eps = (float)adam->eps;
+  a.step_size = (float)(adam->lr / bc1); a.bc2_sqrt = (float)sqrt(bc2);
+  a.packed_valid = adam->packed_valid != 0;
+  rq.adam = &a;
+  if (rq.kind == 0 && n_cols > 0) (void)hipMemsetAsync(col_sums, 0, n_cols * sizeof(float), (hipStream_t)stream);
+  return fused_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream);
+}
+
 }  // extern "C"

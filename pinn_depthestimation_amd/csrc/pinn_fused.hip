@@ -155,6 +155,78 @@ __global__ void k_reduce_grads(Net n, int WP, const float* __restrict__ wg, int 
   if (grp == 0 && i < n.n_params()) grad[i] += (part[0][lane_p] + part[1][lane_p]) + (part[2][lane_p] + part[3][lane_p]);
 }
 
+// One kernel for everything that follows the fused pass in an Adam iteration (pinn_loss_grad_adam_step): the
+// gradient reduction of k_reduce_grads (same partial sums, same order: bit-identical), torch.optim.Adam's update
+// (k_adam's arithmetic, pinn_abi.hip) on the parameter it just summed, the refreshed entries of the packed W / W^T / b
+// the next pass reads (k_pack's mapping, inverted: padding entries stay zero), and — last block — the loss sums of
+// k_reduce_sums.  Five launches of ~4.7 us each become one at the reference's own problem sizes (N_res = 243).
+__global__ void k_finish_adam(Net n, int WP, const float* __restrict__ wg, int copies, int PP, int PW,
+                              const float* __restrict__ wg_sums, int grid, int n_terms, float* __restrict__ term_sums,
+                              int n_cols, float* __restrict__ col_sums, float* __restrict__ grad,
+                              float* __restrict__ params, float* __restrict__ m, float* __restrict__ v,
+                              float* __restrict__ Wp, float* __restrict__ WTp, float* __restrict__ Bp,
+                              float w1, float b2, float w2, float eps, float step_size, float bc2_sqrt) {
+#pragma clang fp contract(off)
+  if (blockIdx.x == gridDim.x - 1) {          // loss sums: double, fixed order (k_reduce_sums)
+    __shared__ double red[256];
+    for (int j = 0; j < n_terms + n_cols; ++j) {
+      const int t = j < n_terms ? j : MSE_SUM0 + (j - n_terms);
+      double a = 0.0;
+      for (int b = threadIdx.x; b < grid; b += 256) a += (double)wg_sums[(int64_t)b * MAX_SUMS + t];
+      red[threadIdx.x] = a;
+      __syncthreads();
+      for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) { if (j < n_terms) term_sums[j] = (float)red[0]; else col_sums[j - n_terms] = (float)red[0]; }
+      __syncthreads();
+    }
+    return;
+  }
+  __shared__ float part[4][64];
+  const int lane_p = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane_p;
+  float s = 0.f;
+  int l = 0, row = 0, col = 0, wo = 0, in_d = 1, out_d = 1;
+  bool is_w = false;
+  if (i < n.n_params()) {
+    l = n.layer_of(i);
+    const int64_t r = i - n.w_off(l);
+    in_d = n.in_dim(l); out_d = n.out_dim(l);
+    const int inP = (l == 0) ? 16 : WP;
+    wo = (l == 0) ? 0 : WP * 16 + (l - 1) * WP * WP;
+    int pidx;
+    is_w = r < (int64_t)in_d * out_d;
+    if (is_w) {   // fragment-native block layout (fused_kernel.h, GradSink)
+      row = (int)(r / in_d); col = (int)(r % in_d);
+      const int ntn = inP / 16;
+      pidx = wo + (((row >> 4) * ntn + (col >> 4)) * 64 + ((row & 15) >> 2) * 16 + (col & 15)) * 4 + (row & 3);
+    } else { row = (int)(r - (int64_t)in_d * out_d); pidx = PW + l * WP + row; }
+    const int per = (copies + 3) / 4;
+    const int c0 = grp * per, c1 = (c0 + per < copies) ? c0 + per : copies;
+    for (int c = c0; c < c1; ++c) s += wg[(int64_t)c * PP + pidx];
+  }
+  part[grp][lane_p] = s;
+  __syncthreads();
+  if (grp == 0 && i < n.n_params()) {
+    const float gi = (part[0][lane_p] + part[1][lane_p]) + (part[2][lane_p] + part[3][lane_p]);
+    grad[i] = gi;
+    const float mi = m[i] + w1 * (gi - m[i]);
+    float vi = v[i] * b2;
+    vi = vi + (w2 * gi) * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    const float pn = params[i] - step_size * (mi / denom);
+    params[i] = pn;
+    if (is_w) {
+      const int inP = (l == 0) ? 16 : WP, outP = (l == n.L) ? 16 : WP;
+      Wp[wo + row * inP + col] = pn;
+      WTp[wo + col * outP + row] = pn;
+    } else Bp[l * WP + row] = pn;
+  }
+}
+
 int run(const Net& n, bool grad, const LossReq* rq, const float* params, const float* X, int64_t N, float* Y,
         float* dY, void* ws, int64_t ws_bytes, hipStream_t s) {
   const Geo g = geo_of(n);
@@ -212,9 +284,11 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
     grid = (int)(P.n_tiles < cap ? (P.n_tiles < 1 ? 1 : P.n_tiles) : cap);
   }
 
+  const AdamReq* adam = rq ? rq->adam : nullptr;
   const int packN = g.PW > g.PB ? g.PW : g.PB;
-  hipLaunchKernelGGL(k_pack, dim3((packN + 255) / 256), dim3(256), 0, s, n, g.WP, params, (float*)(base + w.wp),
-                     (float*)(base + w.wtp), (float*)(base + w.bp), g.PW, g.PB);
+  if (!(adam && adam->packed_valid))
+    hipLaunchKernelGGL(k_pack, dim3((packN + 255) / 256), dim3(256), 0, s, n, g.WP, params, (float*)(base + w.wp),
+                       (float*)(base + w.wtp), (float*)(base + w.bp), g.PW, g.PB);
   if (grad && !P.acc_lds) {   // the workgroups' global gradient copies start from zero
     if (hipMemsetAsync(P.wg_grads, 0, (size_t)grid * g.PP * 4, s) != hipSuccess) {
       set_error("hipMemsetAsync failed"); return PINN_ERR_LAUNCH;
@@ -228,6 +302,15 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
     default: rc = launch_fused<64>(n.K1, grad, P, grid, lds, s); break;
   }
   if (rc) return rc;
+  if (adam) {
+    const int64_t np = n.n_params();
+    hipLaunchKernelGGL(k_finish_adam, dim3((unsigned)((np + 63) / 64) + 1), dim3(256), 0, s, n, g.WP,
+                       (const float*)P.wg_grads, grid, g.PP, g.PW, (const float*)P.wg_sums, grid,
+                       (P.loss_kind & 1) ? rq->n_terms : 0, rq->sums, (P.loss_kind & 2) ? rq->n_cols : 0, rq->mse_sums,
+                       rq->grad, adam->params, adam->m, adam->v, (float*)(base + w.wp), (float*)(base + w.wtp),
+                       (float*)(base + w.bp), adam->w1, adam->b2, adam->w2, adam->eps, adam->step_size, adam->bc2_sqrt);
+    return check_launch("fused finish + adam");
+  }
   if (rq) {
     if (P.loss_kind & 1)
       hipLaunchKernelGGL(k_reduce_sums, dim3(rq->n_terms), dim3(256), 0, s, (const float*)P.wg_sums, grid, 0,
@@ -252,6 +335,16 @@ bool fused_supports(const Net& n, bool want_grad) {
   if (want_grad && n.K1 == 2) return false;   // no k = 1 gradient kernels (no residual of the reference has one direction)
   if (n.fused_kernel == FUSED_KERNEL_COOP && padded_width(n.W) != 64) return false;
   return n.W <= 64 && n.d_in <= 16 && n.d_out <= 16 && n.L >= 1 && n.K1 >= 1 && n.K1 <= 4;
+}
+
+// The folded update needs the whole request in ONE pass (the split request on the width-64 tile kernel runs as two).
+bool fused_supports_adam(const Net& n, const LossReq& rq, int64_t N) {
+  if (!rq.grad || !fused_supports(n, true)) return false;
+  if (rq.kind == 2 && rq.n_split >= 0) {
+    const Geo g = geo_of(n);
+    if (g.WP == 64 && !use_coop(n, g, true, N)) return false;
+  }
+  return true;
 }
 
 int64_t fused_workspace_bytes(const Net& n, int64_t N) {

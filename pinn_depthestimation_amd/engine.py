@@ -159,6 +159,7 @@ class Engine:
         self._cdesc: Dict[Tuple[int, int], PinnDesc] = {}
         self._ws: Dict[int, torch.Tensor] = {}
         self._ws_need: Dict[Tuple[int, int], int] = {}
+        self._packed_tok = None      # (workspace, params storage, params version) after loss_grad_adam_step
         self.dropout_seed = 0        # training-mode dropout: the caller sets a fresh seed per forward pass; the
                                      # reverse sweep of that pass must run under the same one (include/pinn_hip.h)
         cnt = C.c_int64()
@@ -322,8 +323,45 @@ class Engine:
             _ptr(params), _ptr(X), N, int(n_res), _ptr(term_sums), _ptr(col_sums), _ptr(grad), _ptr(ws), ws.numel())
         return term_sums, col_sums
 
+    def loss_grad_adam_step(self, spec: ResidualSpec, term_scale, params, X, n_res: int, grad, m, v, step: int, lr: float,
+                            T: Optional[torch.Tensor] = None, out_col: Sequence[int] = (), col_scale=None,
+                            term_sums=None, col_sums=None, beta1=0.9, beta2=0.999, eps=1e-8) -> bool:
+        """train.py:189-193 in two launches (pinn_loss_grad_adam_step): loss + gradient at `params`, then ONE kernel
+        that finishes sums and gradient, applies Adam to params / m / v and refreshes the packed weights of this N's
+        workspace.  Returns False — nothing launched — when the request is not a one-pass request of the fused engine.
+        The packing kernel is skipped when the previous call on this engine was this method and `params` has not
+        been written since (same storage, same torch version counter, same workspace)."""
+        N, nc = X.shape[0], len(out_col)
+        self._chk(params, "params", (self.n_params,)); self._chk(X, "X", (N, self.desc.d_in))
+        for t, nme in ((grad, "grad"), (m, "exp_avg"), (v, "exp_avg_sq")):
+            self._chk(t, nme, (self.n_params,))
+        self._chk(term_scale, "term_scale", (spec.n_terms,)); self._chk(term_sums, "term_sums", (spec.n_terms,))
+        if nc:
+            self._chk(col_scale, "col_scale", (nc,)); self._chk(col_sums, "col_sums", (nc,))
+            if n_res != N:
+                self._chk(T, "T", (N - n_res if n_res >= 0 else N, nc))
+        ws = self.workspace(N)
+        tok = self._packed_tok
+        packed_valid = tok is not None and tok[0] is ws and tok[1] == params.data_ptr() and tok[2] == params._version
+        self._packed_tok = None
+        st = _lib.PinnAdamState(_ptr(m), _ptr(v), int(step), float(lr), float(beta1), float(beta2), float(eps),
+                                1 if packed_valid else 0, 0)
+        oc = (C.c_int32 * max(nc, 1))(*out_col)
+        idx = self._index()
+        with torch.cuda.device(idx):
+            rc = self.lib.pinn_loss_grad_adam_step(
+                C.byref(self._d()), C.byref(spec.c_struct()), _ptr(term_scale), _ptr(T), nc, oc, _ptr(col_scale),
+                _ptr(params), _ptr(X), N, int(n_res), _ptr(term_sums), _ptr(col_sums), _ptr(grad), C.byref(st), _ptr(ws),
+                ws.numel(), C.c_void_p(torch.cuda.current_stream(idx).cuda_stream))
+        if rc == _lib.ERR_UNSUPPORTED:
+            return False
+        check(rc, "pinn_loss_grad_adam_step")
+        self._packed_tok = (ws, params.data_ptr(), params._version)
+        return True
+
     def adam_step(self, params, grad, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8):
         for t, nme in ((params, "params"), (grad, "grad"), (m, "exp_avg"), (v, "exp_avg_sq")):
             self._chk(t, nme, (self.n_params,))
+        self._packed_tok = None
         self._run("pinn_adam_step", self.lib.pinn_adam_step, _ptr(params), _ptr(grad), _ptr(m), _ptr(v), self.n_params, step, lr, beta1,
                                       beta2, eps)

@@ -77,20 +77,8 @@ class HipEvaluator:
         if (self.merge_sets and Xf is not None and Xr is not None and Xf is not Xr
                 and 0 < Xf.shape[0] <= self.MERGE_MAX_FID and Xr.shape[0] > 0):
             # train.py:131-157 in ONE launch: collocation points first, fidelity points after them
-            # The merged matrix is refreshed whenever either source is a different tensor OBJECT than the
-            # one it was filled from (held here, so its storage cannot be recycled under us): a resampled
-            # mini-batch is a new tensor every call and is copied in every call.  data_ptr() is no
-            # identity — the caching allocator hands a freed block to the next same-sized tensor.
-            nr, nf = Xr.shape[0], Xf.shape[0]
-            if self._cat is None or self._cat.shape[0] != nr + nf:
-                self._cat = torch.empty(nr + nf, Xr.shape[1], dtype=torch.float32, device=Xr.device)
-                self._cat_src = (None, None)
-            if self._cat_src[0] is not Xr:
-                self._cat[:nr].copy_(Xr)
-            if self._cat_src[1] is not Xf:
-                self._cat[nr:].copy_(Xf)
-            self._cat_src = (Xr, Xf)
-            self.eng.residual_mse_split_loss_grad(self.spec, res_scale, Tf, self.fid_cols, fid_scale, theta, self._cat,
+            cat = self._merged(Xr, Xf)
+            self.eng.residual_mse_split_loss_grad(self.spec, res_scale, Tf, self.fid_cols, fid_scale, theta, cat,
                                                   Xr.shape[0], grad, term_sums=res_sums, col_sums=fid_sums)
             return
         if Xf is not None and Xf is Xr and Xr.shape[0] > 0:
@@ -110,6 +98,45 @@ class HipEvaluator:
     def adam_step(self, theta, grad, m, v, step, lr):
         self.eng.adam_step(theta, grad, m, v, step, lr)
 
+    def adam_iteration(self, theta, Xf, Tf, fid_scale, Xr, res_scale, grad, fid_sums, res_sums, m, v, step, lr) -> bool:
+        """loss_func + backward + Adam.step (train.py:189-193) in two launches where the engine can
+        (Engine.loss_grad_adam_step); False — nothing done — otherwise: the caller then runs __call__ + adam_step."""
+        if (self.eng_drop is not None and self.training) or Xr is None or Xr.shape[0] == 0:
+            return False
+        has_fid = Xf is not None and Xf.shape[0] > 0
+        if not has_fid:
+            ok = self.eng.loss_grad_adam_step(self.spec, res_scale, theta, Xr, Xr.shape[0], grad, m, v, step, lr,
+                                              term_sums=res_sums)
+            if ok:
+                fid_sums.zero_()
+            return ok
+        if Xf is Xr:                                       # train_newmethod.py:122-159: one point set for both terms
+            return self.eng.loss_grad_adam_step(self.spec, res_scale, theta, Xr, -1, grad, m, v, step, lr, T=Tf,
+                                                out_col=self.fid_cols, col_scale=fid_scale, term_sums=res_sums,
+                                                col_sums=fid_sums)
+        if not (self.merge_sets and Xf.shape[0] <= self.MERGE_MAX_FID):
+            return False
+        cat = self._merged(Xr, Xf)
+        return self.eng.loss_grad_adam_step(self.spec, res_scale, theta, cat, Xr.shape[0], grad, m, v, step, lr, T=Tf,
+                                            out_col=self.fid_cols, col_scale=fid_scale, term_sums=res_sums,
+                                            col_sums=fid_sums)
+
+    def _merged(self, Xr, Xf):
+        """[collocation points ; fidelity points] in one matrix, refreshed whenever either source is a different
+        tensor OBJECT than the one it was filled from (held here, so its storage cannot be recycled under us): a
+        resampled mini-batch is a new tensor every call and is copied in every call.  data_ptr() is no identity —
+        the caching allocator hands a freed block to the next same-sized tensor."""
+        nr, nf = Xr.shape[0], Xf.shape[0]
+        if self._cat is None or self._cat.shape[0] != nr + nf:
+            self._cat = torch.empty(nr + nf, Xr.shape[1], dtype=torch.float32, device=Xr.device)
+            self._cat_src = (None, None)
+        if self._cat_src[0] is not Xr:
+            self._cat[:nr].copy_(Xr)
+        if self._cat_src[1] is not Xf:
+            self._cat[nr:].copy_(Xf)
+        self._cat_src = (Xr, Xf)
+        return self._cat
+
     def predict(self, theta, X):
         return self.eng.forward(theta, X)
 
@@ -122,10 +149,11 @@ class PINN:
                  reducer: Optional[Reducer] = None, evaluator: Optional[Callable] = None,
                  dnn: Optional[DNN] = None, engine: int = 0, mat_dump_iter: Optional[int] = None,
                  mat_dump_path: str = "data_at50k.mat", residual_batch: Optional[int] = None, seed: int = 1234,
-                 log_flush_every: int = 100, lbfgs_impl: str = "flat", precision: int = 0):
+                 log_flush_every: int = 100, lbfgs_impl: str = "flat", precision: int = 0, fold_adam: bool = True):
         cfg = config if isinstance(config, PinnConfig) else load_config(config)
         self.config, self.device = cfg, torch.device(device)
         self.reducer = reducer or Reducer()
+        self.fold_adam, self._adam_folded = bool(fold_adam), False
         self.layers = cfg.layers                                           # train.py:52-56
         self.dnn = dnn if dnn is not None else DNN(cfg.layers, cfg.dropout_rate, cfg.init_type)
         self.dnn.to(self.device)
@@ -214,21 +242,27 @@ class PINN:
         return a["learning_rate"] * a["scheduler_gamma"] ** (self._sched_steps // a["scheduler_step_size"])
 
     # ---- loss (train.py:128-181) ----------------------------------------------------------------------
-    def loss_func(self) -> torch.Tensor:
-        """Total loss (0-dim device tensor); self.grad holds d loss / d theta afterwards."""
+    def loss_func(self, _adam=None) -> torch.Tensor:
+        """Total loss (0-dim device tensor); self.grad holds d loss / d theta afterwards.  `_adam` (adam_step only):
+        (exp_avg, exp_avg_sq, step, lr) — the evaluator may then fold the Adam update into the pass's last kernel
+        (`self._adam_folded` says whether it did)."""
         self.theta = self.dnn.flat_params()
         if self.mat_dump_iter is not None and self.iter == self.mat_dump_iter:
             self.dump_predictions(self.mat_dump_path)                      # train_newmethod.py:141-153
-        self.buf.zero_()
         if hasattr(self.evaluator, "training"):
             self.evaluator.training = self.dnn.training          # dropout follows the module's mode (train.py:186)
         Xr = self.Xr
         if self.residual_batch is not None:
             idx = torch.randint(0, self.Xr.shape[0], (self.residual_batch,), device=self.device, generator=self._gen)
             Xr = self.Xr.index_select(0, idx)
-        self.evaluator(self.theta, self.Xf, self.Tf, self._fid_scale, Xr, self._res_scale, self.grad,
-                       self._fid_sums, self._res_sums)
-        self.reducer.allreduce_sum_(self.buf)
+        self._adam_folded = _adam is not None and self.evaluator.adam_iteration(
+            self.theta, self.Xf, self.Tf, self._fid_scale, Xr, self._res_scale, self.grad, self._fid_sums, self._res_sums,
+            *_adam)
+        if not self._adam_folded:
+            self.buf.zero_()
+            self.evaluator(self.theta, self.Xf, self.Tf, self._fid_scale, Xr, self._res_scale, self.grad,
+                           self._fid_sums, self._res_sums)
+            self.reducer.allreduce_sum_(self.buf)
         if self._loss_mat is None:
             nf = self._fid_sums.numel()
             m = torch.zeros(3, self.buf.numel() - self.theta.numel(), dtype=torch.float32, device=self.device)
@@ -247,13 +281,17 @@ class PINN:
             self._ring_iters.append(self.iter)
             if len(self._ring_iters) == self._ring.shape[0]:
                 self.flush_log()
-        if self.checkpoint_every:
-            every = self.checkpoint_every
-            if self.config.variant == "newmethod" and self.checkpoint_every == 1000:
-                every = 10000 if self.iter <= 45000 else 1000                                 # train_newmethod.py:181-188
-            if self.iter % every == 0:
-                self.save_checkpoint(f"model_{self.iter}.pth")                                # train.py:175-179
+        if self._checkpoint_due(self.iter):
+            self.save_checkpoint(f"model_{self.iter}.pth")                                    # train.py:175-179
         return loss
+
+    def _checkpoint_due(self, it: int) -> bool:
+        if not self.checkpoint_every:
+            return False
+        every = self.checkpoint_every
+        if self.config.variant == "newmethod" and self.checkpoint_every == 1000:
+            every = 10000 if it <= 45000 else 1000                                            # train_newmethod.py:181-188
+        return it % every == 0
 
     @property
     def history(self) -> List[tuple]:
@@ -317,10 +355,15 @@ class PINN:
     # ---- training (train.py:185-200) ------------------------------------------------------------------
     def adam_step(self):
         """zero_grad / loss_func / backward / Adam.step / StepLR.step (train.py:189-193)."""
-        loss = self.loss_func()
+        # One process, no checkpoint inside this iteration (the reference saves the PRE-update weights from inside
+        # loss_func, train.py:175-179): the evaluator may fold the update into the pass's last kernel.
+        fold = (self.fold_adam and not self.reducer.active and hasattr(self.evaluator, "adam_iteration")
+                and not self._checkpoint_due(self.iter + 1))
+        loss = self.loss_func((self._adam_m, self._adam_v, self._adam_step + 1, self.current_lr()) if fold else None)
         self._adam_step += 1
-        self.evaluator.adam_step(self.theta, self.grad, self._adam_m, self._adam_v, self._adam_step,
-                                 self.current_lr())
+        if not self._adam_folded:
+            self.evaluator.adam_step(self.theta, self.grad, self._adam_m, self._adam_v, self._adam_step,
+                                     self.current_lr())
         self._sched_steps += 1
         return loss
 

@@ -1,0 +1,163 @@
+"""pinn_loss_grad_adam_step: train.py:189-193 (loss_func + backward + Adam.step) in two launches.  The folded kernel
+must give what the separate calls give — the same partial sums in the same order and pinn_adam_step's arithmetic — so
+everything is compared BIT FOR BIT with the loss call followed by pinn_adam_step, over several iterations (the
+second and later ones run on the packed weights the first one left in the workspace).  Bit for bit where the pass itself
+is reproducible (the cooperative kernel: 8 x 64 at small N); the tile kernel accumulates a workgroup's gradient in lock
+order (run-to-run differences of ~1e-6), so there the two runs are compared as two runs of the classic path
+would be."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pinn_oracle as O          # parameter initialisation only
+from pinn_depthestimation_amd import Engine, NetDesc, ResidualSpec
+from pinn_depthestimation_amd._lib import ENGINE_FUSED_COOP, ENGINE_FUSED_TILE, ENGINE_WIDE
+from pinn_depthestimation_amd.trainer import PINN
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # name: d_in, d_out, L, W, grad_cols, residual, inputs, outputs, fid cols, N_res, N_fid (None: newmethod — one point set)
+    "ns8x64_res_only": (3, 4, 8, 64, (0, 1, 2), "Navier_Stokes", ("t", "x", "y"), ("h", "z", "u", "v"), (), 243, 0),
+    "ns8x64_split": (3, 4, 8, 64, (0, 1, 2), "Navier_Stokes", ("t", "x", "y"), ("h", "z", "u", "v"), (2, 3), 243, 12),
+    "pe10x10_split": (2, 6, 10, 10, (0, 1), "physics_equation", ("x", "y"), ("h", "U", "V", "eta_mean", "Hrms", "k"), (0, 1, 2, 3, 4, 5), 243, 12),
+    "co100x20_newmethod": (2, 3, 100, 20, (0, 1), "continuity_only", ("x", "y"), ("U", "V", "h"), (0, 1), 1251, None),
+}
+
+
+def _setup(name, engine=0):
+    d_in, d_out, L, W, gc, res, inn, outn, fid, n_res, n_fid = CASES[name]
+    g = torch.Generator().manual_seed(77)
+    params = O.init_params(O.layer_sizes(d_in, L, W, d_out), "xavier", g)
+    if res == "physics_equation":
+        params[-1][outn.index("h")] = 0.75; params[-1][outn.index("eta_mean")] = 0.0
+    desc = NetDesc(d_in, d_out, L, W, gc, engine=engine)
+    spec = ResidualSpec.from_names(res, inn, desc.grad_cols, outn)
+    nf = n_res if n_fid is None else n_fid
+    X = (torch.rand(n_res + (0 if n_fid is None else n_fid), d_in, generator=g) * 2 - 1).cuda()
+    T = torch.rand(nf, len(fid), generator=g).cuda() if fid else None
+    scale = torch.full((spec.n_terms,), 1.0 / n_res).cuda()
+    cscale = torch.full((len(fid),), 1.0 / max(nf, 1)).cuda() if fid else None
+    return desc, spec, O.flatten(params).cuda(), X, T, scale, cscale, list(fid), (-1 if n_fid is None else n_res)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_folded_iteration_is_bitwise_the_loss_call_plus_adam_step(name):
+    desc, spec, flat0, X, T, scale, cscale, fid, n_res = _setup(name)
+    P = flat0.numel()
+    runs = {}
+    for mode in ("classic", "folded"):
+        eng = Engine(desc)
+        th, m, v, grad = flat0.clone(), torch.zeros(P, device="cuda"), torch.zeros(P, device="cuda"), torch.zeros(P, device="cuda")
+        ts, cs = torch.zeros(spec.n_terms, device="cuda"), torch.zeros(max(len(fid), 1), device="cuda")[:len(fid)]
+        hist = []
+        for step in range(1, 7):
+            lr = 1e-3 * 0.8 ** (step // 3)
+            if step == 4:
+                th.mul_(1.0 + 1e-3)        # a write by torch between iterations: the packed copy must not be trusted
+            if mode == "folded":
+                assert eng.loss_grad_adam_step(spec, scale, th, X, n_res if n_res >= 0 else -1, grad, m, v, step, lr, T=T,
+                                               out_col=fid, col_scale=cscale, term_sums=ts, col_sums=cs if fid else None)
+            else:
+                grad.zero_()
+                if not fid:
+                    eng.residual_loss_grad(spec, scale, th, X, grad, sums=ts)
+                elif n_res < 0:
+                    eng.residual_mse_loss_grad(spec, scale, T, fid, cscale, th, X, grad, term_sums=ts, col_sums=cs)
+                else:
+                    eng.residual_mse_split_loss_grad(spec, scale, T, fid, cscale, th, X, n_res, grad, term_sums=ts, col_sums=cs)
+                eng.adam_step(th, grad, m, v, step, lr)
+            hist.append((ts.clone(), cs.clone(), grad.clone()))
+        torch.cuda.synchronize()
+        runs[mode] = (th, m, v, hist)
+    a, b = runs["classic"], runs["folded"]
+    exact = name.startswith("ns8x64")          # cooperative kernel: reproducible pass
+    same = torch.equal if exact else (lambda x, y: bool(torch.allclose(x, y, rtol=2e-4, atol=1e-7 * float(x.abs().max()))))
+    for k, (ha, hb) in enumerate(zip(a[3], b[3])):
+        assert torch.equal(ha[0], hb[0]) and torch.equal(ha[1], hb[1]) if exact else \
+            torch.allclose(ha[0], hb[0], rtol=1e-5) and torch.allclose(ha[1], hb[1], rtol=1e-5), f"loss sums differ at iteration {k + 1}"
+        rel = float((ha[2] - hb[2]).norm() / ha[2].norm())
+        assert rel == 0.0 if exact else rel < 5e-6, f"gradient differs at iteration {k + 1}: {rel:.2e}"
+    # Adam divides by sqrt(v): a 1e-6 relative difference of a gradient entry moves its parameter by ~lr * 1e-6
+    assert same(a[0], b[0]) and same(a[1], b[1]) and same(a[2], b[2])
+    assert bool(torch.isfinite(b[0]).all()) and float((b[0] - flat0).abs().max()) > 0
+
+
+@pytest.mark.parametrize("engine", [ENGINE_FUSED_TILE, ENGINE_FUSED_COOP])
+def test_folded_iteration_on_both_fused_kernels(engine):
+    """The residual-only request is one pass on either kernel; classic and folded agree bit for bit on each."""
+    desc, spec, flat0, X, T, scale, cscale, fid, n_res = _setup("ns8x64_res_only", engine)
+    P = flat0.numel()
+    out = []
+    for folded in (False, True):
+        eng = Engine(desc)
+        th, m, v, grad = flat0.clone(), torch.zeros(P, device="cuda"), torch.zeros(P, device="cuda"), torch.zeros(P, device="cuda")
+        ts = torch.zeros(spec.n_terms, device="cuda")
+        for step in (1, 2, 3):
+            if folded:
+                assert eng.loss_grad_adam_step(spec, scale, th, X, X.shape[0], grad, m, v, step, 1e-3, term_sums=ts)
+            else:
+                grad.zero_(); eng.residual_loss_grad(spec, scale, th, X, grad, sums=ts); eng.adam_step(th, grad, m, v, step, 1e-3)
+        out.append((th, ts.clone()))
+    if engine == ENGINE_FUSED_COOP:
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    else:                                        # tile kernel: lock-ordered accumulation, see the module docstring
+        assert torch.allclose(out[0][0], out[1][0], rtol=2e-4, atol=1e-7) and torch.allclose(out[0][1], out[1][1], rtol=1e-5)
+
+
+def test_requests_that_are_not_one_fused_pass_are_refused_without_side_effects():
+    # the wide engine, and a split request too large for the cooperative kernel (it runs as two passes)
+    for name, desc_kw, N in (("wide", dict(d_in=3, d_out=4, L=3, W=128), 300), ("big_split", dict(d_in=3, d_out=4, L=8, W=64), 20000)):
+        desc = NetDesc(desc_kw["d_in"], desc_kw["d_out"], desc_kw["L"], desc_kw["W"], (0, 1, 2), engine=ENGINE_WIDE if name == "wide" else 0)
+        spec = ResidualSpec.from_names("Navier_Stokes", ("t", "x", "y"), desc.grad_cols, ("h", "z", "u", "v"))
+        eng = Engine(desc)
+        g = torch.Generator().manual_seed(3)
+        th = torch.randn(desc.n_params, generator=g).mul_(0.1).cuda()
+        X = (torch.rand(N + 12, 3, generator=g) * 2 - 1).cuda()
+        T = torch.rand(12, 2, generator=g).cuda()
+        before = th.clone()
+        m, v, grad = (torch.zeros_like(th) for _ in range(3))
+        ts, cs = torch.zeros(spec.n_terms, device="cuda"), torch.zeros(2, device="cuda")
+        ok = eng.loss_grad_adam_step(spec, torch.ones(spec.n_terms, device="cuda"), th, X, N, grad, m, v, 1, 1e-3, T=T,
+                                     out_col=[2, 3], col_scale=torch.ones(2, device="cuda"), term_sums=ts, col_sums=cs)
+        torch.cuda.synchronize()
+        assert ok is False, name
+        assert torch.equal(th, before) and float(m.abs().max()) == 0.0 and float(grad.abs().max()) == 0.0
+
+
+def _cfg(adam_it, fid_outputs):
+    return {
+        "layers": {"input_features": 3, "hidden_layers": 8, "hidden_width": 64, "output_features": 4},
+        "adam_optimizer": {"max_it": adam_it, "learning_rate": 1e-3, "scheduler_step_size": 7, "scheduler_gamma": 0.8},
+        "lbfgs_optimizer": {"max_it": 0, "learning_rate": 1, "max_evaluation": None, "history_size": 100,
+                            "tolerance_grad": 1e-5, "tolerance_change": 1e-7, "line_search_fn": "strong_wolfe"},
+        "loss": {"weight_fid_loss": 1, "weight_res_loss": 1, **{f"weight_{k}_loss": 1.0 for k in fid_outputs}},
+        "data_fidelity": {"inputs": ["t", "x", "y"], "outputs": list(fid_outputs)},
+        "data_residual": {"inputs": {k: {"requires_grad": ["true"]} for k in "txy"}, "outputs": ["h", "z", "u", "v"]},
+    }
+
+
+@pytest.mark.parametrize("fid_outputs", [(), ("u", "v")])
+def test_trainer_with_and_without_the_folded_update_walks_the_same_trajectory(tmp_path, fid_outputs):
+    """30 Adam iterations with StepLR steps, a checkpoint inside the run (that iteration takes the classic path: the
+    reference saves the pre-update weights from inside loss_func) and per-iteration logging: identical parameters and
+    identical logged losses with fold_adam on and off."""
+    rs = np.random.RandomState(5)
+    Xr = rs.rand(243, 3).astype(np.float32) * 2 - 1
+    Xf = rs.rand(12, 3).astype(np.float32) * 2 - 1 if fid_outputs else None
+    Tf = rs.rand(12, len(fid_outputs)).astype(np.float32) if fid_outputs else None
+    res = {}
+    for fold in (False, True):
+        torch.manual_seed(1234)
+        tr = PINN(Xf, Tf, Xr, _cfg(30, fid_outputs), log_every=1, checkpoint_every=10, log_dir=str(tmp_path / f"f{int(fold)}"),
+                  fold_adam=fold)
+        folded = 0
+        for _ in range(30):
+            tr.adam_step()
+            folded += int(tr._adam_folded)
+        assert folded == (27 if fold else 0)          # iterations 10, 20, 30 save a checkpoint: classic path
+        res[fold] = (tr.dnn.flat_params().clone(), list(tr.history), torch.load(str(tmp_path / f"f{int(fold)}" / "model_20.state.pth"), weights_only=True))
+    assert torch.equal(res[False][0], res[True][0])
+    assert res[False][1] == res[True][1] and len(res[True][1]) == 30
+    for k in res[False][2]:
+        assert torch.equal(res[False][2][k], res[True][2][k]), k
