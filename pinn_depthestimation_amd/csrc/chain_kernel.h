@@ -319,19 +319,6 @@ __device__ __forceinline__ f2 bf2f2(bf8 v, int j) { return f2{bf2f(v[j]), bf2f(v
 // own step (the loop is output-stationary: step MT multiplies the 16 x W slab of output tile MT with the whole
 // input jet), so the activation — the only vector-ALU-heavy part — always has a partner's MFMAs to hide behind,
 // only one or two accumulator tiles are ever live, and the next layer's operand is built piece by piece (`bn`).
-#ifndef PINN_P8_STAGGER
-#define PINN_P8_STAGGER 27         // s_sleep units (64 clocks each) per slot of the start-up spread, 256 slots
-#endif
-// Every workgroup loads its four tiles' a_1 and stores their a_L in one burst per tile batch; started together, all
-// 256 CUs burst together (64 MB at once, ~10 % of the kernel spent waiting on HBM while the matrix pipes idle) and
-// then leave HBM alone for the rest of the batch.  Starts are spread over about one batch's duration instead.
-__device__ __forceinline__ void p8_stagger() {
-  if (PINN_P8_STAGGER > 0) {
-    const int k = (blockIdx.x * 37) & 255;
-    for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(PINN_P8_STAGGER);
-  } else chain_stagger();
-}
-
 template <int NTW, int K1>
 __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_fwd8(const ChainParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -357,7 +344,7 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_fwd8(const ChainParams 
   float* bias_lds = reinterpret_cast<float*>(smem + (R + 1) * SLAB);
   for (int i = threadIdx.x; i < (P.L + 1) * 16 * NTW; i += P8_THREADS) bias_lds[i] = P.bias[i];
   __syncthreads();
-  p8_stagger();
+  chain_stagger();
   // The ring.  A wave's vector-memory operations retire in issue order, so "slab g has landed" is a vmcnt wait for
   // at most the operations issued after its copies.  To make that number a compile-time constant of the step, every
   // step issues the same operations whatever the layer: QD copies (past the last slab: of slab 0 into a spare slot
