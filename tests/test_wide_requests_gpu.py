@@ -1,0 +1,99 @@
+"""The wide engine (64 < W <= 256) on every KIND of loss request, in fp32 and in bf16 mode (chain kernels): the
+fidelity term alone (train.py:131-141: k = 0 network, one quantity per jet), residual + fidelity on one point set
+(train_newmethod.py:122-159), the two point sets of train.py:131-157 in one call, and an odd width / odd K1 / ragged N.
+Checked against the fp64 oracle; tolerances: fp32 2e-6 (loss) / 3e-5 (gradient), bf16 mode 5e-3 / 5e-3 (the bound the
+engine is tested to on the reference's 12 x 256 golden, tests/test_config3_gpu.py)."""
+import pytest
+import torch
+
+from oracle import pinn_oracle as O
+from pinn_depthestimation_amd import Engine, NetDesc, ResidualSpec
+from pinn_depthestimation_amd._lib import ENGINE_WIDE, PREC_BF16, PREC_F32
+from tests.test_engine_gpu import oracle_loss_and_grad, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+NETS = {
+    # name: d_in, d_out, L, W, grad_cols, residual, inputs, outputs
+    "ns_4x256": (3, 4, 4, 256, (0, 1, 2), "Navier_Stokes", ("t", "x", "y"), ("h", "z", "u", "v")),
+    "co_3x100": (2, 3, 3, 100, (0, 1), "continuity_only", ("x", "y"), ("U", "V", "h")),     # K1 = 3, width not a multiple of 16
+}
+TOL = {PREC_F32: (2e-6, 3e-5), PREC_BF16: (5e-3, 5e-3)}
+
+
+def _net(name, N, seed=99):
+    d_in, d_out, L, W, gc, res, inn, outn = NETS[name]
+    g = torch.Generator().manual_seed(seed)
+    params = O.init_params(O.layer_sizes(d_in, L, W, d_out), "xavier", g)
+    X = torch.rand(N, d_in, generator=g) * 2 - 1
+    if res == "continuity_only":
+        X[:, 0] = X[:, 0] * 40
+    desc = NetDesc(d_in, d_out, L, W, gc, engine=ENGINE_WIDE)
+    return params, X, desc, ResidualSpec.from_names(res, inn, desc.grad_cols, outn), res, inn, outn, g
+
+
+@pytest.mark.parametrize("prec", [PREC_F32, PREC_BF16])
+@pytest.mark.parametrize("name", list(NETS))
+def test_fidelity_term_alone(name, prec):
+    params, X, desc, spec, res, inn, outn, g = _net(name, 237)
+    nc = min(2, desc.d_out)
+    T = torch.rand(237, nc, generator=g)
+    w = [1.0, 2.5][:nc]
+    p = [q.double().requires_grad_(True) for q in params]
+    lo = O.fidelity_loss(p, X.double(), T.double(), list(range(nc)), w)
+    go = O.flat_grad(lo, p)
+    eng = Engine(desc.with_(precision=prec))
+    grad = torch.zeros(desc.n_params, device="cuda")
+    scale = (torch.tensor(w) / 237).cuda()
+    sums = eng.mse_loss_grad(O.flatten(params).cuda(), X.cuda().contiguous(), T.cuda(), list(range(nc)), scale, grad)
+    loss = float((sums.double() * scale.double()).sum())
+    el, eg = abs(loss - float(lo)) / float(lo), rel_l2(grad.cpu(), go)
+    print(f"{name} prec={prec} fidelity only: loss {el:.2e} grad {eg:.2e}")
+    assert el < TOL[prec][0] and eg < TOL[prec][1]
+
+
+@pytest.mark.parametrize("prec", [PREC_F32, PREC_BF16])
+@pytest.mark.parametrize("name", list(NETS))
+def test_residual_and_fidelity_requests_agree_with_the_separate_calls_and_the_oracle(name, prec):
+    N, NF = 1237, 70                                       # ragged: 77.3 and 4.4 tiles
+    params, X, desc, spec, res, inn, outn, g = _net(name, N + NF)
+    T = torch.rand(NF, 2, generator=g).cuda()
+    eng = Engine(desc.with_(precision=prec))
+    flat, Xd = O.flatten(params).cuda(), X.cuda().contiguous()
+    if res == "continuity_only":
+        cnt = float((X[:N, 0] < 25.5).sum())
+        ts = torch.tensor([1.0 / N, 1.0 / cnt, 0.0]).cuda()
+    else:
+        ts = torch.full((spec.n_terms,), 1.0 / N).cuda()
+    cs = torch.tensor([0.7 / NF, 1.3 / NF]).cuda()
+    # oracle: residual on the first N points
+    l64, g64 = oracle_loss_and_grad(params, X[:N], res, inn, outn, desc.grad_cols, torch.float64)
+    p = [q.double().requires_grad_(True) for q in params]
+    lf = O.fidelity_loss(p, X[N:].double(), T.cpu().double(), [0, 1], [0.7, 1.3])
+    gf = O.flat_grad(lf, p)
+    # separate calls
+    g1 = torch.zeros(desc.n_params, device="cuda")
+    s_res = eng.residual_loss_grad(spec, ts, flat, Xd[:N].contiguous(), g1)
+    s_mse = eng.mse_loss_grad(flat, Xd[N:].contiguous(), T, [0, 1], cs, g1)
+    # the two point sets in one call
+    g2 = torch.zeros(desc.n_params, device="cuda")
+    t_sums, c_sums = eng.residual_mse_split_loss_grad(spec, ts, T, [0, 1], cs, flat, Xd, N, g2)
+    tl, tg = TOL[prec]
+    loss_sep = float((s_res.double() * ts.double()).sum() + (s_mse.double() * cs.double()).sum())
+    loss_one = float((t_sums.double() * ts.double()).sum() + (c_sums.double() * cs.double()).sum())
+    ref = float(l64) + float(lf)
+    print(f"{name} prec={prec}: separate {abs(loss_sep - ref) / ref:.2e} one call {abs(loss_one - ref) / ref:.2e} "
+          f"grad {rel_l2(g1.cpu(), g64 + gf):.2e} / {rel_l2(g2.cpu(), g64 + gf):.2e}")
+    assert abs(loss_sep - ref) / ref < tl and abs(loss_one - ref) / ref < tl
+    assert rel_l2(g1.cpu(), g64 + gf) < tg and rel_l2(g2.cpu(), g64 + gf) < tg
+    # one point set for both terms (train_newmethod.py): equals residual + fidelity on those points
+    Tn = torch.rand(N, 2, generator=torch.Generator().manual_seed(5)).cuda()
+    csn = torch.tensor([0.7 / N, 1.3 / N]).cuda()
+    g3 = torch.zeros(desc.n_params, device="cuda")
+    a_res = eng.residual_loss_grad(spec, ts, flat, Xd[:N].contiguous(), g3)
+    a_mse = eng.mse_loss_grad(flat, Xd[:N].contiguous(), Tn, [0, 1], csn, g3)
+    g4 = torch.zeros(desc.n_params, device="cuda")
+    b_res, b_mse = eng.residual_mse_loss_grad(spec, ts, Tn, [0, 1], csn, flat, Xd[:N].contiguous(), g4)
+    rt = 1e-5 if prec == PREC_F32 else 5e-3
+    assert torch.allclose(a_res, b_res, rtol=rt) and torch.allclose(a_mse, b_mse, rtol=rt)
+    assert rel_l2(g4.cpu(), g3.cpu()) < (2e-5 if prec == PREC_F32 else 5e-3)
