@@ -77,6 +77,12 @@ struct ChainParams {
   int n_slices;               // wgrad: point slices per layer
   int64_t w_off1, w_per;      // flat offsets: W_1 at w_off1, W_{l+1} - W_l = w_per; b_l at w_off(l) + W*W
   unsigned long long* diag;   // -DPINN_CHAIN_DIAG builds only: per-phase cycle sums of workgroup 0 / wave 0
+  // first layer folded into k_chain_fwd8 (d_in <= 3): a_1 is computed from the coordinates, never loaded
+  const float* X;             // (n_points, d_in) row-major, the WHOLE point set
+  const float* W0;            // padded first-layer weights, row-major [WP][16] fp32 (wide engine's k_wide_pack)
+  int64_t n_points, tile0;    // points in X; index of this chunk's first tile
+  int d_in;
+  int dir_col[3];             // input column of tangent 1, 2, 3
 };
 
 // Diagnostic build (-DPINN_CHAIN_DIAG, tools/chain_diag.sh): s_memtime stamps per phase, summed by one wave.
@@ -319,7 +325,10 @@ __device__ __forceinline__ f2 bf2f2(bf8 v, int j) { return f2{bf2f(v[j]), bf2f(v
 // own step (the loop is output-stationary: step MT multiplies the 16 x W slab of output tile MT with the whole
 // input jet), so the activation — the only vector-ALU-heavy part — always has a partner's MFMAs to hide behind,
 // only one or two accumulator tiles are ever live, and the next layer's operand is built piece by piece (`bn`).
-template <int NTW, int K1>
+// FOLD (d_in <= 3, every network of the reference): the first layer is part of this kernel.  z = W_0 x + b_0 is three
+// FMAs per unit and its tangents are columns of W_0, so a tile's a_1 is computed in registers from 12 bytes per point
+// instead of being written by one kernel (2 KB per point) and read back by this one.
+template <int NTW, int K1, bool FOLD>
 __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_fwd8(const ChainParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NS = NTW / 2;
@@ -343,6 +352,10 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_fwd8(const ChainParams 
   const int64_t my_tb = (n_tb - blockIdx.x + gridDim.x - 1) / gridDim.x;
   float* bias_lds = reinterpret_cast<float*>(smem + (R + 1) * SLAB);
   for (int i = threadIdx.x; i < (P.L + 1) * 16 * NTW; i += P8_THREADS) bias_lds[i] = P.bias[i];
+  f4* w0_lds = reinterpret_cast<f4*>(bias_lds + (P.L + 1) * 16 * NTW);      // FOLD: (W_0[u][0..2], 0) per unit
+  if constexpr (FOLD) {
+    for (int i = threadIdx.x; i < 16 * NTW; i += P8_THREADS) w0_lds[i] = f4{P.W0[i * 16], P.W0[i * 16 + 1], P.W0[i * 16 + 2], 0.f};
+  }
   __syncthreads();
   chain_stagger();
   // The ring.  A wave's vector-memory operations retire in issue order, so "slab g has landed" is a vmcnt wait for
@@ -391,24 +404,59 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_fwd8(const ChainParams 
 #pragma unroll
       for (int s = 0; s < NS; ++s) st_blk(dstL, G == NG - 1 ? lvo_last : lvo, (2 * G * NS + s) * 1024, bn[G][s]);
   };
+  // FOLD: this lane's point of batch tb_ -> its coordinates (three loads whatever d_in: missing columns and points
+  // beyond the set read as 0 from an out-of-range offset), then the tile's a_1 from them
+  float xr[3] = {0.f, 0.f, 0.f};
+  const __amdgpu_buffer_rsrc_t xrs = jet_rsrc(P.X, (int)(P.n_points * P.d_in * 4 < 0x7fffffff ? P.n_points * P.d_in * 4 : 0x7fffffff));
+  auto load_x = [&](int64_t tb_) {
+    int64_t t_ = tb_ * CHAIN_WAVES + (wave >> 1);
+    if (t_ >= P.n_tiles) t_ = P.n_tiles - 1;
+    const int64_t pt = (P.tile0 + t_) * 16 + 8 * half + p8;
+    const bool ok = tb_ < n_tb && pt < P.n_points;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const unsigned off = ok && j < P.d_in ? (unsigned)(pt * P.d_in + j) * 4u : 0x7ffffff0u;
+      xr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)off, 0, 0));
+    }
+  };
+  auto make_a1 = [&]() {
+    // tangent c (quantity 2G + par >= 1) of the input is the unit vector of column dir_col[c - 1]: z-dot = W_0[u][that column]
+    const int cA = P.dir_col[0], cB = P.dir_col[1], cC = P.dir_col[2];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int u = 32 * s + 16 * (j >> 2) + 4 * q + (j & 3);
+        const f4 w = w0_lds[u];
+        const float z = fmaf(w[2], xr[2], fmaf(w[1], xr[1], fmaf(w[0], xr[0], bias_lds[u])));
+        const float av = tanh_bf(z), sv = fmaf(-av, av, 1.f);
+        auto col = [&](int cc) { return cc == 0 ? w[0] : (cc == 1 ? w[1] : w[2]); };
+        const float t1 = sv * col(cA), t2 = sv * col(cB), t3 = sv * col(cC);
+        bj[0][s][j] = (__bf16)(par ? (K1 > 1 ? t1 : 0.f) : av);
+        if constexpr (NG > 1) bj[1][s][j] = (__bf16)(par ? (K1 > 3 ? t3 : 0.f) : t2);
+      }
+  };
   bool live = false, prev_live = false, next_live = false;
   int64_t tbase = tile_of(blockIdx.x, live), prev_base = 0, next_base = 0;
-  load_a1(tbase, true);
+  if constexpr (FOLD) load_x(blockIdx.x); else load_a1(tbase, true);
   for (int64_t tb = blockIdx.x; tb < n_tb; tb += gridDim.x) {
+    if constexpr (FOLD) make_a1();
+    else {
 #pragma unroll
-    for (int G = 0; G < NG; ++G)
+      for (int G = 0; G < NG; ++G)
 #pragma unroll
-      for (int s = 0; s < NS; ++s) bj[G][s] = bx[G][s];
+        for (int s = 0; s < NS; ++s) bj[G][s] = bx[G][s];
+    }
     store_aL(prev_base, prev_live);
     CHAIN_STAMP(6);
     for (int l = 1; l <= nh; ++l) {
       f4 accp[NG];
-      // a_l (l >= 2; a_1 is in memory already) goes out during this layer's steps, one block pair per step
-      const __amdgpu_buffer_rsrc_t dst = jet_rsrc(P.A + (int64_t)(l - 1) * P.jet_stride + tbase, live && P.spill && l >= 2 ? TILE_BYTES : 0);
+      // a_l goes out during this layer's steps (a_1 only if this kernel made it: otherwise it is in memory already)
+      const __amdgpu_buffer_rsrc_t dst = jet_rsrc(P.A + (int64_t)(l - 1) * P.jet_stride + tbase, live && P.spill && (l >= 2 || FOLD) ? TILE_BYTES : 0);
       const float* bl = bias_lds + l * (16 * NTW);
       if (l == nh) {
         next_base = tile_of(tb + gridDim.x, next_live);
-        load_a1(next_base, tb + gridDim.x < n_tb);
+        if constexpr (FOLD) load_x(tb + gridDim.x); else load_a1(next_base, tb + gridDim.x < n_tb);
       }
       // activation of output tile M: the value lanes (group 0, par 0) take tanh(z + b); every other column of the
       // point is a tangent and is scaled by the point's 1 - a^2 (one row rotate away for the par-1 lanes)
@@ -449,10 +497,12 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_fwd8(const ChainParams 
           // the first R - 1 steps of a layer, what was issued at its start: the a_L stores of the previous batch
           // (first layer), the a_1 loads of the next one (last layer)
           constexpr int N = (R - 2) * QD + p8_younger_stores<NST, NTW, R, MT, true, true>();
-          static_assert(N + 2 * NST <= 63, "vmcnt range");
+          constexpr int NLD = FOLD ? 3 : NST;          // loads issued at the start of the last layer
+          static_assert(N + NST + NLD <= 63, "vmcnt range");
           if (MT < R - 1 && (l == 1 || l == nh)) {
-            if (l == 1 && l == nh) wait_vm<N + 2 * NST>();
-            else wait_vm<N + NST>();
+            if (l == 1 && l == nh) wait_vm<N + NST + NLD>();
+            else if (l == 1) wait_vm<N + NST>();
+            else wait_vm<N + NLD>();
           } else wait_vm<N>();
         }
         CHAIN_STAMP(0);
@@ -833,7 +883,7 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_wgrad8(const ChainParam
   }
 }
 
-template <int NTW> int launch_chain_fwd8(int K1, const ChainParams& P, int grid, hipStream_t s);
+template <int NTW> int launch_chain_fwd8(int K1, bool fold_first, const ChainParams& P, int grid, hipStream_t s);
 template <int NTW> int launch_chain_bwd(int K1, const ChainParams& P, int grid, hipStream_t s);
 template <int NTW> int launch_chain_wgrad8(int K1, const ChainParams& P, int grid, hipStream_t s);
 

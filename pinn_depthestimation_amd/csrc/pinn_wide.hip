@@ -240,12 +240,16 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
 #endif
       auto jetA = [&](int l) { return (float*)(base + w.jA + (int64_t)(l - 1) * w.jet_stride); };   // a_l, l = 1..L
       const int cgrid = (int)((Lp.n_tiles + CHAIN_WAVES - 1) / CHAIN_WAVES < w.grid ? (Lp.n_tiles + CHAIN_WAVES - 1) / CHAIN_WAVES : w.grid);
+      // d_in <= 3 (every network of the reference): the first layer is folded into the forward chain kernel
+      const bool fold_first = nh > 0 && n.d_in <= 3;
+      C.X = X; C.W0 = Wp; C.n_points = N; C.tile0 = Lp.tile0; C.d_in = n.d_in;
+      for (int j = 0; j < 3; ++j) C.dir_col[j] = j < n.k ? n.dir_col[j] : 0;
       Lp.W = Wp; Lp.b = Bp; Lp.out_act = jetA(1);
-      rc = launch_wide_fwd<NTW>(0, K1, prec, false, P, Lp, grid, s); if (rc) break;
+      if (!fold_first) { rc = launch_wide_fwd<NTW>(0, K1, prec, false, P, Lp, grid, s); if (rc) break; }
 #ifdef PINN_CHAIN_DIAG
       C.diag = dbuf;
 #endif
-      if (nh > 0) { rc = launch_chain_fwd8<NTW>(K1, C, cgrid, s); if (rc) break; }
+      if (nh > 0) { rc = launch_chain_fwd8<NTW>(K1, fold_first, C, cgrid, s); if (rc) break; }
       Lp.W = Wp + woff(L); Lp.b = Bp + L * g.WP; Lp.in_act = jetA(L); Lp.out_act = nullptr; Lp.g_out = gout;
       rc = launch_wide_fwd<NTW>(2, K1, prec, grad, P, Lp, grid, s); if (rc) break;
 #ifdef PINN_CHAIN_DIAG
