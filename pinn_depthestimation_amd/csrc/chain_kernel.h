@@ -883,8 +883,96 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_wgrad8(const ChainParam
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// First layer, reverse (d_in <= 3): zbar_0 = adjoint(abar_1, a_1) and the layer's gradient
+//   dW_0[u][j] = sum_p ( zbar_0(u,p) x_j(p) + sum_c zbar_c(u,p) [dir_col(c) == j] ),   db_0[u] = sum_p zbar_0(u,p)
+// in ONE streaming pass over abar_1 (k_chain_bwd's output) and a_1 — 2 x 2 KB per point read, nothing written but
+// W x 4 sums.  (The wide engine's two kernels for this wrote zbar_0 back over abar_1 and read it again.)
+// A wave walks tiles; lane (p, q) holds the 8 units of k-step s of its point; every product is summed over the tile's
+// 16 points with four DPP row rotates, lane p keeps the two sums it owns and adds them to the workgroup's [W][4] table
+// in LDS; one global atomic per table entry and workgroup at the end.
+__device__ __forceinline__ float dpp_row_sum16(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+  return v;
+}
+
+template <int NTW, int K1>
+__global__ __launch_bounds__(CHAIN_THREADS, 2) void k_chain_first_bwd(const ChainParams P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NS = NTW / 2;
+  constexpr int TILE_BYTES = K1 * NS * 1024;
+  float* tab = reinterpret_cast<float*>(smem);                 // [16 NTW units][4]: dW_0 columns 0..2, db_0
+  for (int i = threadIdx.x; i < 64 * NTW; i += CHAIN_THREADS) tab[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = lane & 15, q = lane >> 4;
+  const unsigned lpos = (4u * p + q) * 16u;
+  const __amdgpu_buffer_rsrc_t xrs = jet_rsrc(P.X, (int)(P.n_points * P.d_in * 4 < 0x7fffffff ? P.n_points * P.d_in * 4 : 0x7fffffff));
+  const int cA = P.dir_col[0], cB = P.dir_col[1], cC = P.dir_col[2];
+  for (int64_t t = (int64_t)blockIdx.x * CHAIN_WAVES + wave; t < P.n_tiles; t += (int64_t)gridDim.x * CHAIN_WAVES) {
+    const int64_t tbase = uniform64(t) * (K1 * NS * 512);
+    const __amdgpu_buffer_rsrc_t gr = jet_rsrc(P.G1 + tbase, TILE_BYTES), ar = jet_rsrc(P.A + tbase, TILE_BYTES);
+    const int64_t pt = (P.tile0 + t) * 16 + p;
+    float x[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const unsigned off = pt < P.n_points && j < P.d_in ? (unsigned)(pt * P.d_in + j) * 4u : 0x7ffffff0u;
+      x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)off, 0, 0));
+    }
+    const bool valid = pt < P.n_points;                        // padding points of the last tile carry no adjoint
+#pragma unroll 2
+    for (int s = 0; s < NS; ++s) {
+      bf8 gv[K1], av[K1];
+#pragma unroll
+      for (int c = 0; c < K1; ++c) { gv[c] = ld_blk(gr, lpos, (c * NS + s) * 1024); av[c] = ld_blk(ar, lpos, (c * NS + s) * 1024); }
+      float own0 = 0.f, own1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float a = bf2f(av[0][j]);
+        const float sv = fmaf(-a, a, 1.f);
+        float zc[K1], cross = 0.f;
+#pragma unroll
+        for (int c = 1; c < K1; ++c) { const float g = bf2f(gv[c][j]); cross = fmaf(g, bf2f(av[c][j]), cross); zc[c] = g * sv; }
+        zc[0] = fmaf(-2.f * a, cross, sv * bf2f(gv[0][j]));
+        float w[4] = {zc[0] * x[0], zc[0] * x[1], zc[0] * x[2], zc[0]};
+        if constexpr (K1 > 1) {
+          const int dc[3] = {cA, cB, cC};
+#pragma unroll
+          for (int c = 1; c < K1; ++c) {
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) w[jj] += dc[c - 1] == jj ? zc[c] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float tot = dpp_row_sum16(valid ? w[i] : 0.f);
+          const int vidx = j * 4 + i;                          // lane p owns value vidx with (vidx & 15) == p
+          if ((vidx >> 4) == 0) own0 = p == (vidx & 15) ? tot : own0;
+          else own1 = p == (vidx & 15) ? tot : own1;
+        }
+      }
+      // slot k: value 16 k + p  <->  j = 4 k + (p >> 2), component p & 3  <->  unit 32 s + 16 k + 4 q + (p >> 2)
+      atomicAdd(&tab[(32 * s + 4 * q + (p >> 2)) * 4 + (p & 3)], own0);
+      atomicAdd(&tab[(32 * s + 16 + 4 * q + (p >> 2)) * 4 + (p & 3)], own1);
+    }
+  }
+  __syncthreads();
+  // flat torch layout: W_0 (out, in) row-major at offset 0, then b_0
+  for (int i = threadIdx.x; i < 64 * NTW; i += CHAIN_THREADS) {
+    const int u = i >> 2, comp = i & 3;
+    if (u >= P.W) continue;
+    const float v = tab[i];
+    if (comp == 3) __hip_atomic_fetch_add(P.dW + (int64_t)P.W * P.d_in + u, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (comp < P.d_in) __hip_atomic_fetch_add(P.dW + (int64_t)u * P.d_in + comp, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 template <int NTW> int launch_chain_fwd8(int K1, bool fold_first, const ChainParams& P, int grid, hipStream_t s);
 template <int NTW> int launch_chain_bwd(int K1, const ChainParams& P, int grid, hipStream_t s);
 template <int NTW> int launch_chain_wgrad8(int K1, const ChainParams& P, int grid, hipStream_t s);
+template <int NTW> int launch_chain_first_bwd(int K1, const ChainParams& P, int grid, hipStream_t s);
 
 }  // namespace pinn

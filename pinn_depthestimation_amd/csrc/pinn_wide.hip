@@ -273,12 +273,20 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
       C.diag = dbuf + 8;
 #endif
       if (nh > 0) { rc = launch_chain_bwd<NTW>(K1, C, cgrid, s); if (rc) break; }
-      // first layer: zbar_0 = adjoint(abar_1, a_1), in place over abar_1; dW_0 = zbar_0 . (x, e_j)^T
-      Lp.g_in = (float*)C.G1; Lp.in_act = jetA(1); Lp.g_out = nullptr; Lp.W = nullptr; Lp.z_out = (float*)C.G1;
-      rc = launch_wide_bwd<NTW>(0, K1, prec, P, Lp, grid, s); if (rc) break;
-      Lp.g_in = (float*)C.G1; Lp.in_act = nullptr; Lp.in_d = n.in_dim(0); Lp.out_d = n.out_dim(0);
-      Lp.dW = rq->grad + n.w_off(0); Lp.db = rq->grad + n.b_off(0);
-      rc = launch_wide_wgrad<NTW>(0, K1, prec, P, Lp, w.grid, s); if (rc) break;
+      if (fold_first) {
+        // first layer: zbar_0 = adjoint(abar_1, a_1) and dW_0, db_0 in one streaming pass (k_chain_first_bwd)
+        ChainParams F = C;
+        F.A = (unsigned short*)jetA(1); F.dW = rq->grad;
+        const int64_t want = (Lp.n_tiles + CHAIN_WAVES - 1) / CHAIN_WAVES;
+        rc = launch_chain_first_bwd<NTW>(K1, F, (int)(want < 8 * (int64_t)w.grid ? want : 8 * (int64_t)w.grid), s); if (rc) break;
+      } else {
+        // first layer: zbar_0 = adjoint(abar_1, a_1), in place over abar_1; dW_0 = zbar_0 . (x, e_j)^T
+        Lp.g_in = (float*)C.G1; Lp.in_act = jetA(1); Lp.g_out = nullptr; Lp.W = nullptr; Lp.z_out = (float*)C.G1;
+        rc = launch_wide_bwd<NTW>(0, K1, prec, P, Lp, grid, s); if (rc) break;
+        Lp.g_in = (float*)C.G1; Lp.in_act = nullptr; Lp.in_d = n.in_dim(0); Lp.out_d = n.out_dim(0);
+        Lp.dW = rq->grad + n.w_off(0); Lp.db = rq->grad + n.b_off(0);
+        rc = launch_wide_wgrad<NTW>(0, K1, prec, P, Lp, w.grid, s); if (rc) break;
+      }
       if (nh > 0) {
         C.n_slices = w.grid / nh > 0 ? w.grid / nh : 1;
         if ((int64_t)C.n_slices > Lp.n_tiles) C.n_slices = (int)Lp.n_tiles;
