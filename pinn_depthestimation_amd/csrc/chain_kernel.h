@@ -83,6 +83,11 @@ struct ChainParams {
   int64_t n_points, tile0;    // points in X; index of this chunk's first tile
   int d_in;
   int dir_col[3];             // input column of tangent 1, 2, 3
+  // last layer's reverse pass in one kernel (k_chain_last_bwd, d_out <= 4)
+  const float* gout;          // G: [tile][quantity][256] fp32, lane (p, q) x 4: outputs 4q .. 4q+3 of point p (k_wide_fwd)
+  const float* WLT;           // padded transposed last-layer weights [WP][16] fp32
+  float* dWL;                 // flat gradient of W_L (d_out, W) row-major, then b_L
+  int d_out;
 };
 
 // Diagnostic build (-DPINN_CHAIN_DIAG, tools/chain_diag.sh): s_memtime stamps per phase, summed by one wave.
@@ -970,9 +975,77 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_chain_first_bwd(const Chai
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Last layer, reverse (d_out <= 4): abar_L = W_L^T G (the reverse chain's input, bf16 chain layout) and the layer's gradient
+//   dW_L[o][u] = sum over points and quantities G_c[o](p) a_L,c[u](p),   db_L[o] = sum_p G_0[o](p)
+// in ONE streaming pass over a_L (2 KB per point read, 2 KB written) — the wide engine's two kernels for this read a_L
+// and G separately.  Same shape as k_chain_first_bwd: row sums by DPP, the workgroup's [W][4] table in LDS.
+template <int NTW, int K1>
+__global__ __launch_bounds__(CHAIN_THREADS, 2) void k_chain_last_bwd(const ChainParams P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NS = NTW / 2;
+  constexpr int TILE_BYTES = K1 * NS * 1024;
+  f4* wlt = reinterpret_cast<f4*>(smem);                        // [16 NTW units]: W_L[0..3][u]
+  float* tab = reinterpret_cast<float*>(wlt + 16 * NTW);        // [16 NTW units][4]: dW_L; then db_L[4]
+  for (int i = threadIdx.x; i < 16 * NTW; i += CHAIN_THREADS) wlt[i] = *reinterpret_cast<const f4*>(P.WLT + i * 16);
+  for (int i = threadIdx.x; i < 64 * NTW + 4; i += CHAIN_THREADS) tab[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = lane & 15, q = lane >> 4;
+  const unsigned lpos = (4u * p + q) * 16u;
+  for (int64_t t = (int64_t)blockIdx.x * CHAIN_WAVES + wave; t < P.n_tiles; t += (int64_t)gridDim.x * CHAIN_WAVES) {
+    const int64_t tbase = uniform64(t) * (K1 * NS * 512);
+    const __amdgpu_buffer_rsrc_t ar = jet_rsrc(P.A + tbase, TILE_BYTES), glr = jet_rsrc(P.GL + tbase, TILE_BYTES);
+    f4 G[K1];
+#pragma unroll
+    for (int c = 0; c < K1; ++c) G[c] = *reinterpret_cast<const f4*>(P.gout + ((uniform64(t) * K1 + c) * 256 + p * 4));
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const float tot = dpp_row_sum16(G[0][o]);
+      if (lane == 0) atomicAdd(&tab[64 * NTW + o], tot);
+    }
+#pragma unroll 2
+    for (int s = 0; s < NS; ++s) {
+      bf8 av[K1], gb[K1];
+#pragma unroll
+      for (int c = 0; c < K1; ++c) av[c] = ld_blk(ar, lpos, (c * NS + s) * 1024);
+      float own0 = 0.f, own1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const f4 wl = wlt[32 * s + 16 * (j >> 2) + 4 * q + (j & 3)];
+#pragma unroll
+        for (int c = 0; c < K1; ++c)
+          gb[c][j] = (__bf16)fmaf(wl[3], G[c][3], fmaf(wl[2], G[c][2], fmaf(wl[1], G[c][1], wl[0] * G[c][0])));
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          float w = 0.f;
+#pragma unroll
+          for (int c = 0; c < K1; ++c) w = fmaf(G[c][o], bf2f(av[c][j]), w);
+          const float tot = dpp_row_sum16(w);
+          const int vidx = j * 4 + o;                          // lane p owns value vidx with (vidx & 15) == p
+          if ((vidx >> 4) == 0) own0 = p == (vidx & 15) ? tot : own0;
+          else own1 = p == (vidx & 15) ? tot : own1;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < K1; ++c) st_blk(glr, lpos, (c * NS + s) * 1024, gb[c]);
+      atomicAdd(&tab[(32 * s + 4 * q + (p >> 2)) * 4 + (p & 3)], own0);
+      atomicAdd(&tab[(32 * s + 16 + 4 * q + (p >> 2)) * 4 + (p & 3)], own1);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * NTW + 4; i += CHAIN_THREADS) {
+    const float v = tab[i];
+    if (i >= 64 * NTW) { if (i - 64 * NTW < P.d_out) __hip_atomic_fetch_add(P.dWL + (int64_t)P.d_out * P.W + (i - 64 * NTW), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    else if ((i >> 2) < P.W && (i & 3) < P.d_out)
+      __hip_atomic_fetch_add(P.dWL + (int64_t)(i & 3) * P.W + (i >> 2), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 template <int NTW> int launch_chain_fwd8(int K1, bool fold_first, const ChainParams& P, int grid, hipStream_t s);
 template <int NTW> int launch_chain_bwd(int K1, const ChainParams& P, int grid, hipStream_t s);
 template <int NTW> int launch_chain_wgrad8(int K1, const ChainParams& P, int grid, hipStream_t s);
 template <int NTW> int launch_chain_first_bwd(int K1, const ChainParams& P, int grid, hipStream_t s);
+template <int NTW> int launch_chain_last_bwd(int K1, const ChainParams& P, int grid, hipStream_t s);
 
 }  // namespace pinn

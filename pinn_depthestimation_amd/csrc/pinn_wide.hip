@@ -263,12 +263,19 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
       }
 #endif
       if (!grad) continue;
-      // output layer: dW_L = G . a_L^T ; abar_L = W_L^T G (bf16, chain layout)
-      Lp.g_in = gout; Lp.in_act = jetA(L); Lp.in_d = n.in_dim(L); Lp.out_d = n.out_dim(L);
-      Lp.dW = rq->grad + n.w_off(L); Lp.db = rq->grad + n.b_off(L);
-      rc = launch_wide_wgrad<NTW>(2, K1, prec, P, Lp, w.grid, s); if (rc) break;
-      Lp.W = WTp + woff(L); Lp.g_out = (float*)C.GL;
-      rc = launch_wide_bwd<NTW>(2, K1, prec, P, Lp, grid, s); if (rc) break;
+      // output layer: dW_L = G . a_L^T ; abar_L = W_L^T G (bf16, chain layout) — one streaming kernel when d_out <= 4
+      if (n.d_out <= 4) {
+        ChainParams F = C;
+        F.A = (unsigned short*)jetA(L); F.gout = gout; F.WLT = WTp + woff(L); F.dWL = rq->grad + n.w_off(L); F.d_out = n.d_out;
+        const int64_t want = (Lp.n_tiles + CHAIN_WAVES - 1) / CHAIN_WAVES;
+        rc = launch_chain_last_bwd<NTW>(K1, F, (int)(want < 8 * (int64_t)w.grid ? want : 8 * (int64_t)w.grid), s); if (rc) break;
+      } else {
+        Lp.g_in = gout; Lp.in_act = jetA(L); Lp.in_d = n.in_dim(L); Lp.out_d = n.out_dim(L);
+        Lp.dW = rq->grad + n.w_off(L); Lp.db = rq->grad + n.b_off(L);
+        rc = launch_wide_wgrad<NTW>(2, K1, prec, P, Lp, w.grid, s); if (rc) break;
+        Lp.W = WTp + woff(L); Lp.g_out = (float*)C.GL;
+        rc = launch_wide_bwd<NTW>(2, K1, prec, P, Lp, grid, s); if (rc) break;
+      }
 #ifdef PINN_CHAIN_DIAG
       C.diag = dbuf + 8;
 #endif
