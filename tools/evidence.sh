@@ -5,7 +5,7 @@
 R="$(cd "$(dirname "$0")/.." && pwd)"
 TAG=$1; shift
 OUT=$R/gpurun_out/evidence_$TAG
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py "$@" > $OUT/bench.json 2> $OUT/bench.log || { echo bench failed; tail -5 $OUT/bench.log; exit 1; }
 cat $OUT/bench.json
