@@ -21,6 +21,7 @@
  *   pinn_lbfgs_push / pinn_lbfgs_direction  torch.optim.LBFGS's two-loop recursion (train.py:116-125,200)
  *   pinn_adam_step          torch.optim.Adam.step as called at train.py:192
  *   pinn_loss_grad_adam_step  train.py:189-193 (loss_func + backward + Adam.step) in two launches
+ *   pinn_adam_loop          train.py:188-193, n iterations of the above enqueued by one call
  *
  * Conventions
  *   - plain C, no exceptions; every function returns 0 on success, <0 on error;
@@ -198,6 +199,8 @@ int32_t pinn_residual_mse_split_loss_grad(const pinn_desc* desc, const pinn_resi
  *   X, n_res: as pinn_residual_mse_split_loss_grad (n_res == N: residual term only, n_cols may be 0;
  *             n_res < 0: both terms on every point, train_newmethod.py:122-159).
  *   grad_flat is OVERWRITTEN with this iteration's gradient (no zero-fill needed).
+ *   adam->loss_rows / losses: optional — the finishing kernel also forms the weighted loss values the loop logs
+ *             (double accumulation over the few sums), saving the caller a launch per iteration.
  *   adam->packed_valid: nonzero iff the previous call on this `ws` was this function with the same desc and
  *             nothing has written params since — the call then skips the packing kernel.
  * Returns PINN_ERR_UNSUPPORTED, having launched nothing, when the request would not run as one pass of the fused
@@ -208,7 +211,9 @@ typedef struct pinn_adam_state {
   int64_t step;          /* 1-based, as torch counts */
   double lr, beta1, beta2, eps;
   int32_t packed_valid;
-  int32_t reserved;
+  int32_t n_loss_rows;   /* 0, or: also write losses[r] = sum_j loss_rows[r][j] * S_j, S = [col_sums (n_cols) | term_sums] */
+  const float* loss_rows;/* (n_loss_rows, n_cols + n_terms) row-major weights (train.py:141,154,157: fidelity / residual / total) */
+  float* losses;         /* (n_loss_rows) */
 } pinn_adam_state;
 int32_t pinn_loss_grad_adam_step(const pinn_desc* desc, const pinn_residual_spec* spec,
                                  const float* term_scale, const float* T, int32_t n_cols,
@@ -216,6 +221,20 @@ int32_t pinn_loss_grad_adam_step(const pinn_desc* desc, const pinn_residual_spec
                                  float* params, const float* X, int64_t N, int64_t n_res,
                                  float* term_sums, float* col_sums, float* grad_flat,
                                  const pinn_adam_state* adam, void* ws, int64_t ws_bytes, void* stream);
+
+/* n_iters consecutive Adam iterations of pinn_loss_grad_adam_step on the same point set (train.py:188-193, the
+ * `for epoch in range(adam_maxit)` loop without the host in it: 2 n_iters launches enqueued by one call; at the
+ * reference's problem sizes the Python-side cost of an iteration had become as large as its kernels).  Iteration i uses
+ * step adam->step + i and learning rate lr[i] (HOST array: the StepLR schedule, train.py:109-113); when
+ * adam->n_loss_rows > 0 it writes its weighted losses to adam->losses + i * n_loss_rows.  adam->lr is ignored.
+ * Same refusal rule as pinn_loss_grad_adam_step (nothing is launched when unsupported). */
+int32_t pinn_adam_loop(const pinn_desc* desc, const pinn_residual_spec* spec,
+                       const float* term_scale, const float* T, int32_t n_cols,
+                       const int32_t* out_col, const float* col_scale,
+                       float* params, const float* X, int64_t N, int64_t n_res,
+                       float* term_sums, float* col_sums, float* grad_flat,
+                       const pinn_adam_state* adam, int32_t n_iters, const double* lr,
+                       void* ws, int64_t ws_bytes, void* stream);
 
 /* torch.optim.Adam single-tensor update on flat buffers (amsgrad off, weight_decay 0,
  * maximize off): m,v are exp_avg / exp_avg_sq; step is the 1-based step count;

@@ -42,7 +42,8 @@ class PinnResidualSpec(C.Structure):
 class PinnAdamState(C.Structure):
     _fields_ = [
         ("m", C.c_void_p), ("v", C.c_void_p), ("step", C.c_int64), ("lr", C.c_double), ("beta1", C.c_double),
-        ("beta2", C.c_double), ("eps", C.c_double), ("packed_valid", C.c_int32), ("reserved", C.c_int32),
+        ("beta2", C.c_double), ("eps", C.c_double), ("packed_valid", C.c_int32), ("n_loss_rows", C.c_int32),
+        ("loss_rows", C.c_void_p), ("losses", C.c_void_p),
     ]
 
 
@@ -87,6 +88,9 @@ _SIGNATURES = {
     "pinn_loss_grad_adam_step": (C.c_int32, [C.POINTER(PinnDesc), C.POINTER(PinnResidualSpec), _P, _P, C.c_int32,
                                              C.POINTER(C.c_int32), _P, _P, _P, C.c_int64, C.c_int64, _P, _P, _P,
                                              C.POINTER(PinnAdamState), _P, C.c_int64, _P]),
+    "pinn_adam_loop": (C.c_int32, [C.POINTER(PinnDesc), C.POINTER(PinnResidualSpec), _P, _P, C.c_int32,
+                                   C.POINTER(C.c_int32), _P, _P, _P, C.c_int64, C.c_int64, _P, _P, _P,
+                                   C.POINTER(PinnAdamState), C.c_int32, C.POINTER(C.c_double), _P, C.c_int64, _P]),
 }
 
 _lib = None

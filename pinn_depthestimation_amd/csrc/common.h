@@ -62,6 +62,7 @@ struct AdamReq {
   float* m; float* v;
   float w1, b2, w2, eps, step_size, bc2_sqrt;   // as pinn_adam_step forms them
   bool packed_valid;    // the workspace's packed weights already equal params (left there by the previous call)
+  int n_loss_rows; const float* loss_rows; float* losses;   // optional weighted loss values (see pinn_adam_state)
 };
 
 struct LossReq {

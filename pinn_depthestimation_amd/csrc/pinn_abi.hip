@@ -399,9 +399,31 @@ int32_t pinn_loss_grad_adam_step(const pinn_desc* desc, const pinn_residual_spec
   a.w1 = (float)(1.0 - adam->beta1); a.b2 = (float)adam->beta2; a.w2 = (float)(1.0 - adam->beta2); a.eps = (float)adam->eps;
   a.step_size = (float)(adam->lr / bc1); a.bc2_sqrt = (float)sqrt(bc2);
   a.packed_valid = adam->packed_valid != 0;
+  if (adam->n_loss_rows < 0 || adam->n_loss_rows > 8 || (adam->n_loss_rows > 0 && (!adam->loss_rows || !adam->losses))) {
+    set_error("bad loss_rows arguments"); return PINN_ERR_INVALID;
+  }
+  a.n_loss_rows = adam->n_loss_rows; a.loss_rows = adam->loss_rows; a.losses = adam->losses;
   rq.adam = &a;
   if (rq.kind == 0 && n_cols > 0) (void)hipMemsetAsync(col_sums, 0, n_cols * sizeof(float), (hipStream_t)stream);
   return fused_loss(n, rq, params, X, N, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int32_t pinn_adam_loop(const pinn_desc* desc, const pinn_residual_spec* spec, const float* term_scale, const float* T,
+                       int32_t n_cols, const int32_t* out_col, const float* col_scale, float* params, const float* X,
+                       int64_t N, int64_t n_res, float* term_sums, float* col_sums, float* grad_flat,
+                       const pinn_adam_state* adam, int32_t n_iters, const double* lr, void* ws, int64_t ws_bytes,
+                       void* stream) {
+  if (!adam || !lr || n_iters < 0) { set_error("bad arguments"); return PINN_ERR_INVALID; }
+  for (int32_t i = 0; i < n_iters; ++i) {
+    pinn_adam_state st = *adam;
+    st.step = adam->step + i; st.lr = lr[i];
+    st.packed_valid = (i > 0 || adam->packed_valid) ? 1 : 0;
+    if (adam->n_loss_rows > 0 && adam->losses) st.losses = adam->losses + (int64_t)i * adam->n_loss_rows;
+    const int32_t rc = pinn_loss_grad_adam_step(desc, spec, term_scale, T, n_cols, out_col, col_scale, params, X, N, n_res,
+                                                term_sums, col_sums, grad_flat, &st, ws, ws_bytes, stream);
+    if (rc) return rc;      // (unsupported requests are refused by the first iteration, before anything is launched)
+  }
+  return PINN_OK;
 }
 
 }  // extern "C"

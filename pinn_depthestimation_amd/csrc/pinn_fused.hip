@@ -165,10 +165,12 @@ __global__ void k_finish_adam(Net n, int WP, const float* __restrict__ wg, int c
                               int n_cols, float* __restrict__ col_sums, float* __restrict__ grad,
                               float* __restrict__ params, float* __restrict__ m, float* __restrict__ v,
                               float* __restrict__ Wp, float* __restrict__ WTp, float* __restrict__ Bp,
-                              float w1, float b2, float w2, float eps, float step_size, float bc2_sqrt) {
+                              float w1, float b2, float w2, float eps, float step_size, float bc2_sqrt,
+                              int n_loss_rows, const float* __restrict__ loss_rows, float* __restrict__ losses) {
 #pragma clang fp contract(off)
   if (blockIdx.x == gridDim.x - 1) {          // loss sums: double, fixed order (k_reduce_sums)
     __shared__ double red[256];
+    __shared__ double ssum[2 * PINN_MAX_ROLES + 8];     // [col sums | term sums], for the optional weighted losses
     for (int j = 0; j < n_terms + n_cols; ++j) {
       const int t = j < n_terms ? j : MSE_SUM0 + (j - n_terms);
       double a = 0.0;
@@ -179,8 +181,16 @@ __global__ void k_finish_adam(Net n, int WP, const float* __restrict__ wg, int c
         if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
       }
-      if (threadIdx.x == 0) { if (j < n_terms) term_sums[j] = (float)red[0]; else col_sums[j - n_terms] = (float)red[0]; }
+      if (threadIdx.x == 0) {
+        if (j < n_terms) { term_sums[j] = (float)red[0]; ssum[n_cols + j] = (double)(float)red[0]; }
+        else { col_sums[j - n_terms] = (float)red[0]; ssum[j - n_terms] = (double)(float)red[0]; }
+      }
       __syncthreads();
+    }
+    if ((int)threadIdx.x < n_loss_rows) {
+      double a = 0.0;
+      for (int j = 0; j < n_cols + n_terms; ++j) a += (double)loss_rows[threadIdx.x * (n_cols + n_terms) + j] * ssum[j];
+      losses[threadIdx.x] = (float)a;
     }
     return;
   }
@@ -308,7 +318,8 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
                        (const float*)P.wg_grads, grid, g.PP, g.PW, (const float*)P.wg_sums, grid,
                        (P.loss_kind & 1) ? rq->n_terms : 0, rq->sums, (P.loss_kind & 2) ? rq->n_cols : 0, rq->mse_sums,
                        rq->grad, adam->params, adam->m, adam->v, (float*)(base + w.wp), (float*)(base + w.wtp),
-                       (float*)(base + w.bp), adam->w1, adam->b2, adam->w2, adam->eps, adam->step_size, adam->bc2_sqrt);
+                       (float*)(base + w.bp), adam->w1, adam->b2, adam->w2, adam->eps, adam->step_size, adam->bc2_sqrt,
+                       adam->n_loss_rows, adam->loss_rows, adam->losses);
     return check_launch("fused finish + adam");
   }
   if (rq) {

@@ -323,15 +323,20 @@ class Engine:
             _ptr(params), _ptr(X), N, int(n_res), _ptr(term_sums), _ptr(col_sums), _ptr(grad), _ptr(ws), ws.numel())
         return term_sums, col_sums
 
-    def loss_grad_adam_step(self, spec: ResidualSpec, term_scale, params, X, n_res: int, grad, m, v, step: int, lr: float,
+    def loss_grad_adam_step(self, spec: ResidualSpec, term_scale, params, X, n_res: int, grad, m, v, step: int, lr,
                             T: Optional[torch.Tensor] = None, out_col: Sequence[int] = (), col_scale=None,
-                            term_sums=None, col_sums=None, beta1=0.9, beta2=0.999, eps=1e-8) -> bool:
+                            term_sums=None, col_sums=None, beta1=0.9, beta2=0.999, eps=1e-8,
+                            loss_rows: Optional[torch.Tensor] = None, losses: Optional[torch.Tensor] = None) -> bool:
         """train.py:189-193 in two launches (pinn_loss_grad_adam_step): loss + gradient at `params`, then ONE kernel
         that finishes sums and gradient, applies Adam to params / m / v and refreshes the packed weights of this N's
-        workspace.  Returns False — nothing launched — when the request is not a one-pass request of the fused engine.
+        workspace; with `loss_rows` (rows x (len(out_col) + n_terms)) it also writes losses = loss_rows @ [col sums | term sums].
+        `lr` a sequence of n learning rates: n consecutive iterations (steps step .. step + n - 1) enqueued by ONE call
+        (pinn_adam_loop), iteration i writing losses[i].
+        Returns False — nothing launched — when the request is not a one-pass request of the fused engine.
         The packing kernel is skipped when the previous call on this engine was this method and `params` has not
         been written since (same storage, same torch version counter, same workspace)."""
         N, nc = X.shape[0], len(out_col)
+        lrs = [float(x) for x in lr] if isinstance(lr, (list, tuple)) else None
         self._chk(params, "params", (self.n_params,)); self._chk(X, "X", (N, self.desc.d_in))
         for t, nme in ((grad, "grad"), (m, "exp_avg"), (v, "exp_avg_sq")):
             self._chk(t, nme, (self.n_params,))
@@ -340,22 +345,30 @@ class Engine:
             self._chk(col_scale, "col_scale", (nc,)); self._chk(col_sums, "col_sums", (nc,))
             if n_res != N:
                 self._chk(T, "T", (N - n_res if n_res >= 0 else N, nc))
+        n_rows = 0
+        if loss_rows is not None:
+            n_rows = loss_rows.shape[0]
+            self._chk(loss_rows, "loss_rows", (n_rows, nc + spec.n_terms))
+            self._chk(losses, "losses", (n_rows,) if lrs is None else (len(lrs), n_rows))
         ws = self.workspace(N)
         tok = self._packed_tok
         packed_valid = tok is not None and tok[0] is ws and tok[1] == params.data_ptr() and tok[2] == params._version
         self._packed_tok = None
-        st = _lib.PinnAdamState(_ptr(m), _ptr(v), int(step), float(lr), float(beta1), float(beta2), float(eps),
-                                1 if packed_valid else 0, 0)
+        st = _lib.PinnAdamState(_ptr(m), _ptr(v), int(step), 0.0 if lrs is not None else float(lr), float(beta1), float(beta2),
+                                float(eps), 1 if packed_valid else 0, n_rows, _ptr(loss_rows), _ptr(losses))
         oc = (C.c_int32 * max(nc, 1))(*out_col)
         idx = self._index()
+        head = (C.byref(self._d()), C.byref(spec.c_struct()), _ptr(term_scale), _ptr(T), nc, oc, _ptr(col_scale),
+                _ptr(params), _ptr(X), N, int(n_res), _ptr(term_sums), _ptr(col_sums), _ptr(grad), C.byref(st))
         with torch.cuda.device(idx):
-            rc = self.lib.pinn_loss_grad_adam_step(
-                C.byref(self._d()), C.byref(spec.c_struct()), _ptr(term_scale), _ptr(T), nc, oc, _ptr(col_scale),
-                _ptr(params), _ptr(X), N, int(n_res), _ptr(term_sums), _ptr(col_sums), _ptr(grad), C.byref(st), _ptr(ws),
-                ws.numel(), C.c_void_p(torch.cuda.current_stream(idx).cuda_stream))
+            tail = (_ptr(ws), ws.numel(), C.c_void_p(torch.cuda.current_stream(idx).cuda_stream))
+            if lrs is None:
+                rc = self.lib.pinn_loss_grad_adam_step(*head, *tail)
+            else:
+                rc = self.lib.pinn_adam_loop(*head, len(lrs), (C.c_double * len(lrs))(*lrs), *tail)
         if rc == _lib.ERR_UNSUPPORTED:
             return False
-        check(rc, "pinn_loss_grad_adam_step")
+        check(rc, "pinn_loss_grad_adam_step" if lrs is None else "pinn_adam_loop")
         self._packed_tok = (ws, params.data_ptr(), params._version)
         return True
 

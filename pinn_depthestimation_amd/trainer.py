@@ -98,28 +98,28 @@ class HipEvaluator:
     def adam_step(self, theta, grad, m, v, step, lr):
         self.eng.adam_step(theta, grad, m, v, step, lr)
 
-    def adam_iteration(self, theta, Xf, Tf, fid_scale, Xr, res_scale, grad, fid_sums, res_sums, m, v, step, lr) -> bool:
+    def adam_iteration(self, theta, Xf, Tf, fid_scale, Xr, res_scale, grad, fid_sums, res_sums, m, v, step, lr,
+                       loss_rows=None, losses=None) -> bool:
         """loss_func + backward + Adam.step (train.py:189-193) in two launches where the engine can
         (Engine.loss_grad_adam_step); False — nothing done — otherwise: the caller then runs __call__ + adam_step."""
         if (self.eng_drop is not None and self.training) or Xr is None or Xr.shape[0] == 0:
             return False
         has_fid = Xf is not None and Xf.shape[0] > 0
         if not has_fid:
-            ok = self.eng.loss_grad_adam_step(self.spec, res_scale, theta, Xr, Xr.shape[0], grad, m, v, step, lr,
-                                              term_sums=res_sums)
-            if ok:
-                fid_sums.zero_()
-            return ok
+            if fid_sums.numel():       # (a configuration with fidelity outputs but no fidelity points: classic path)
+                return False
+            return self.eng.loss_grad_adam_step(self.spec, res_scale, theta, Xr, Xr.shape[0], grad, m, v, step, lr,
+                                                term_sums=res_sums, loss_rows=loss_rows, losses=losses)
         if Xf is Xr:                                       # train_newmethod.py:122-159: one point set for both terms
             return self.eng.loss_grad_adam_step(self.spec, res_scale, theta, Xr, -1, grad, m, v, step, lr, T=Tf,
                                                 out_col=self.fid_cols, col_scale=fid_scale, term_sums=res_sums,
-                                                col_sums=fid_sums)
+                                                col_sums=fid_sums, loss_rows=loss_rows, losses=losses)
         if not (self.merge_sets and Xf.shape[0] <= self.MERGE_MAX_FID):
             return False
         cat = self._merged(Xr, Xf)
         return self.eng.loss_grad_adam_step(self.spec, res_scale, theta, cat, Xr.shape[0], grad, m, v, step, lr, T=Tf,
                                             out_col=self.fid_cols, col_scale=fid_scale, term_sums=res_sums,
-                                            col_sums=fid_sums)
+                                            col_sums=fid_sums, loss_rows=loss_rows, losses=losses)
 
     def _merged(self, Xr, Xf):
         """[collocation points ; fidelity points] in one matrix, refreshed whenever either source is a different
@@ -153,7 +153,7 @@ class PINN:
         cfg = config if isinstance(config, PinnConfig) else load_config(config)
         self.config, self.device = cfg, torch.device(device)
         self.reducer = reducer or Reducer()
-        self.fold_adam, self._adam_folded = bool(fold_adam), False
+        self.fold_adam, self._adam_folded, self._folded_iters, self._run_losses = bool(fold_adam), False, 0, None
         self.layers = cfg.layers                                           # train.py:52-56
         self.dnn = dnn if dnn is not None else DNN(cfg.layers, cfg.dropout_rate, cfg.init_type)
         self.dnn.to(self.device)
@@ -255,26 +255,21 @@ class PINN:
         if self.residual_batch is not None:
             idx = torch.randint(0, self.Xr.shape[0], (self.residual_batch,), device=self.device, generator=self._gen)
             Xr = self.Xr.index_select(0, idx)
+        self._ensure_loss_mat()
+        nxt = self.iter + 1
+        logged = nxt % self.log_every == 0 or nxt % 1000 == 0
+        # the three losses of a logged iteration are computed straight into the device-side ring
+        vec = self._ring[len(self._ring_iters)] if logged else self._loss_vec
         self._adam_folded = _adam is not None and self.evaluator.adam_iteration(
             self.theta, self.Xf, self.Tf, self._fid_scale, Xr, self._res_scale, self.grad, self._fid_sums, self._res_sums,
-            *_adam)
+            *_adam, loss_rows=self._loss_mat, losses=vec)
         if not self._adam_folded:
             self.buf.zero_()
             self.evaluator(self.theta, self.Xf, self.Tf, self._fid_scale, Xr, self._res_scale, self.grad,
                            self._fid_sums, self._res_sums)
             self.reducer.allreduce_sum_(self.buf)
-        if self._loss_mat is None:
-            nf = self._fid_sums.numel()
-            m = torch.zeros(3, self.buf.numel() - self.theta.numel(), dtype=torch.float32, device=self.device)
-            m[0, :nf] = self._fid_unit
-            m[1, nf:] = self._res_unit
-            m[2] = self.weight_fidelity * m[0] + self.weight_residual * m[1]                  # train.py:157
-            self._loss_mat = m
+            torch.mv(self._loss_mat, self.buf[self.theta.numel():], out=vec)                  # one small mat-vec: the three losses
         self.iter += 1                                                                        # train.py:160
-        logged = self.iter % self.log_every == 0 or self.iter % 1000 == 0
-        # one small mat-vec gives the three losses; a logged iteration computes them straight into the ring
-        vec = torch.mv(self._loss_mat, self.buf[self.theta.numel():],
-                       out=self._ring[len(self._ring_iters)] if logged else None)
         fidelity_loss, residual_loss, loss = vec[0], vec[1], vec[2]
         self.last = (fidelity_loss, residual_loss, loss)
         if logged:
@@ -284,6 +279,16 @@ class PINN:
         if self._checkpoint_due(self.iter):
             self.save_checkpoint(f"model_{self.iter}.pth")                                    # train.py:175-179
         return loss
+
+    def _ensure_loss_mat(self):
+        if self._loss_mat is None:
+            nf = self._fid_sums.numel()
+            m = torch.zeros(3, self.buf.numel() - self.theta.numel(), dtype=torch.float32, device=self.device)
+            m[0, :nf] = self._fid_unit
+            m[1, nf:] = self._res_unit
+            m[2] = self.weight_fidelity * m[0] + self.weight_residual * m[1]                  # train.py:157
+            self._loss_mat = m.contiguous()
+            self._loss_vec = torch.zeros(3, dtype=torch.float32, device=self.device)
 
     def _checkpoint_due(self, it: int) -> bool:
         if not self.checkpoint_every:
@@ -364,8 +369,82 @@ class PINN:
         if not self._adam_folded:
             self.evaluator.adam_step(self.theta, self.grad, self._adam_m, self._adam_v, self._adam_step,
                                      self.current_lr())
+        else:
+            self._folded_iters += 1
         self._sched_steps += 1
         return loss
+
+    MAX_RUN = 256      # iterations enqueued by one call (pinn_adam_loop)
+
+    def _foldable_run(self, n: int) -> int:
+        """How many of the next n Adam iterations can be enqueued by ONE call: full batch, one process, nothing the
+        host must do in between (a checkpoint is saved from inside loss_func with pre-update weights, train.py:175-179;
+        the prediction dump of train_newmethod.py:141-153 happens at the start of its iteration)."""
+        if not (self.fold_adam and not self.reducer.active and hasattr(self.evaluator, "adam_iteration")
+                and self.residual_batch is None):
+            return 0
+        k = min(n, self.MAX_RUN)
+        for i in range(1, k + 1):
+            if self._checkpoint_due(self.iter + i):
+                k = i - 1
+                break
+        if self.mat_dump_iter is not None and self.iter <= self.mat_dump_iter < self.iter + k:
+            k = self.mat_dump_iter - self.iter
+        free, logged = self._ring.shape[0] - len(self._ring_iters), 0
+        for i in range(1, k + 1):
+            it = self.iter + i
+            if it % self.log_every == 0 or it % 1000 == 0:
+                logged += 1
+                if logged > free:
+                    k = i - 1
+                    break
+        return k
+
+    def train_adam(self, n: int):
+        """n Adam iterations (train.py:188-193).  Runs of iterations that need nothing from the host are enqueued by one
+        call (two launches per iteration, no Python in between); the rest go through adam_step()."""
+        while n > 0:
+            k = self._foldable_run(n)
+            if k > 1 and self._adam_run(k):
+                n -= k
+                continue
+            self.adam_step()
+            n -= 1
+
+    def _adam_run(self, k: int) -> bool:
+        self.theta = self.dnn.flat_params()
+        self._ensure_loss_mat()
+        if hasattr(self.evaluator, "training"):
+            self.evaluator.training = self.dnn.training
+        a = self.config.adam
+        lrs = [a["learning_rate"] * a["scheduler_gamma"] ** ((self._sched_steps + i) // a["scheduler_step_size"]) for i in range(k)]
+        if self._run_losses is None or self._run_losses.shape[0] < k:
+            self._run_losses = torch.zeros(max(k, self.MAX_RUN), 3, dtype=torch.float32, device=self.device)
+        out = self._run_losses[:k]
+        if not self.evaluator.adam_iteration(self.theta, self.Xf, self.Tf, self._fid_scale, self.Xr, self._res_scale, self.grad,
+                                             self._fid_sums, self._res_sums, self._adam_m, self._adam_v, self._adam_step + 1,
+                                             lrs, loss_rows=self._loss_mat, losses=out):
+            return False
+        if self.log_every == 1:                      # every iteration logged: one copy into the ring
+            r0 = len(self._ring_iters)
+            self._ring[r0:r0 + k].copy_(out)
+            self._ring_iters.extend(range(self.iter + 1, self.iter + k + 1))
+        else:
+            for i in range(k):
+                it = self.iter + 1 + i
+                if it % self.log_every == 0 or it % 1000 == 0:
+                    self._ring[len(self._ring_iters)].copy_(out[i])
+                    self._ring_iters.append(it)
+        self.iter += k
+        self._adam_step += k
+        self._sched_steps += k
+        self._folded_iters += k
+        self._adam_folded = True
+        last = out[k - 1].clone()
+        self.last = (last[0], last[1], last[2])
+        if len(self._ring_iters) == self._ring.shape[0]:
+            self.flush_log()
+        return True
 
     def closure(self):
         """train.py:195-199"""
@@ -375,8 +454,7 @@ class PINN:
 
     def train(self):
         self.dnn.train()
-        for _ in range(self.adam_maxit):
-            self.adam_step()
+        self.train_adam(self.adam_maxit)
         if self.config.lbfgs["max_it"] > 0:
             self.optimizer_LBFGS.step(self.closure)                                # ONE step, train.py:200
         self.flush_log()

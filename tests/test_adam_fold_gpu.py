@@ -105,6 +105,20 @@ def test_folded_iteration_on_both_fused_kernels(engine):
         assert torch.allclose(out[0][0], out[1][0], rtol=2e-4, atol=1e-7) and torch.allclose(out[0][1], out[1][1], rtol=1e-5)
 
 
+def test_weighted_losses_from_the_finishing_kernel():
+    desc, spec, flat0, X, T, scale, cscale, fid, n_res = _setup("ns8x64_split")
+    P = flat0.numel()
+    eng = Engine(desc)
+    th, m, v, grad = flat0.clone(), torch.zeros(P, device="cuda"), torch.zeros(P, device="cuda"), torch.zeros(P, device="cuda")
+    ts, cs = torch.zeros(spec.n_terms, device="cuda"), torch.zeros(len(fid), device="cuda")
+    rows = torch.rand(3, len(fid) + spec.n_terms, generator=torch.Generator().manual_seed(2)).cuda()
+    out = torch.zeros(3, device="cuda")
+    assert eng.loss_grad_adam_step(spec, scale, th, X, n_res, grad, m, v, 1, 1e-3, T=T, out_col=fid, col_scale=cscale,
+                                   term_sums=ts, col_sums=cs, loss_rows=rows, losses=out)
+    ref = rows.double() @ torch.cat([cs, ts]).double()
+    assert torch.allclose(out.double(), ref, rtol=1e-6)
+
+
 def test_requests_that_are_not_one_fused_pass_are_refused_without_side_effects():
     # the wide engine, and a split request too large for the cooperative kernel (it runs as two passes)
     for name, desc_kw, N in (("wide", dict(d_in=3, d_out=4, L=3, W=128), 300), ("big_split", dict(d_in=3, d_out=4, L=8, W=64), 20000)):
@@ -141,7 +155,7 @@ def _cfg(adam_it, fid_outputs):
 def test_trainer_with_and_without_the_folded_update_walks_the_same_trajectory(tmp_path, fid_outputs):
     """30 Adam iterations with StepLR steps, a checkpoint inside the run (that iteration takes the classic path: the
     reference saves the pre-update weights from inside loss_func) and per-iteration logging: identical parameters and
-    identical logged losses with fold_adam on and off."""
+    the same logged losses (to fp32 rounding of the final weighted sum) with fold_adam on and off."""
     rs = np.random.RandomState(5)
     Xr = rs.rand(243, 3).astype(np.float32) * 2 - 1
     Xf = rs.rand(12, 3).astype(np.float32) * 2 - 1 if fid_outputs else None
@@ -151,13 +165,17 @@ def test_trainer_with_and_without_the_folded_update_walks_the_same_trajectory(tm
         torch.manual_seed(1234)
         tr = PINN(Xf, Tf, Xr, _cfg(30, fid_outputs), log_every=1, checkpoint_every=10, log_dir=str(tmp_path / f"f{int(fold)}"),
                   fold_adam=fold)
-        folded = 0
-        for _ in range(30):
-            tr.adam_step()
-            folded += int(tr._adam_folded)
-        assert folded == (27 if fold else 0)          # iterations 10, 20, 30 save a checkpoint: classic path
+        if fold:
+            tr.train_adam(30)                         # runs of 9 iterations per call between the checkpoints
+        else:
+            for _ in range(30):
+                tr.adam_step()
+        assert tr._folded_iters == (27 if fold else 0)    # iterations 10, 20, 30 save a checkpoint: classic path
+        assert tr.iter == 30 and tr._adam_step == 30
         res[fold] = (tr.dnn.flat_params().clone(), list(tr.history), torch.load(str(tmp_path / f"f{int(fold)}" / "model_20.state.pth"), weights_only=True))
     assert torch.equal(res[False][0], res[True][0])
-    assert res[False][1] == res[True][1] and len(res[True][1]) == 30
+    # the logged losses: the folded kernel forms them in double from the same sums, the classic path by an fp32 mat-vec
+    assert len(res[True][1]) == 30 and [r[0] for r in res[True][1]] == [r[0] for r in res[False][1]]
+    assert np.allclose(np.array(res[True][1])[:, 1:], np.array(res[False][1])[:, 1:], rtol=2e-6, atol=0.0)
     for k in res[False][2]:
         assert torch.equal(res[False][2][k], res[True][2][k]), k
