@@ -111,3 +111,33 @@ def test_abi_call_argument_validation_returns_before_any_launch(lib):
     lib.pinn_query_workspace(C.byref(desc), 1000, C.byref(need))
     assert lib.pinn_forward(C.byref(desc), fake, fake, 1000, fake, fake, need.value - 1, NULL) == WORKSPACE
     assert str(need.value) in err(lib)
+
+
+def test_abi_folded_adam_iteration_validation(lib):
+    """pinn_loss_grad_adam_step / pinn_adam_loop: argument checks and the refusal of requests that are not one pass of the
+    fused engine happen on the host, before anything is launched (fake non-NULL device pointers are never dereferenced)."""
+    fake = C.c_void_p(4096)
+    good = NetDesc(3, 4, 8, 64, (0, 1, 2))
+    spec = ResidualSpec.from_names("Navier_Stokes", ("t", "x", "y"), good.grad_cols, ("h", "z", "u", "v"))
+    st = _lib.PinnAdamState(fake, fake, 1, 1e-3, 0.9, 0.999, 1e-8, 0, 0, None, None)
+    oc = (C.c_int32 * 1)(0)
+
+    def call(desc, adam, n_cols=0, n_res=100, N=100):
+        return lib.pinn_loss_grad_adam_step(C.byref(desc.c_struct()), C.byref(spec.c_struct()), fake, fake, n_cols, oc, fake,
+                                            fake, fake, N, n_res, fake, fake, fake, adam, fake, 1 << 30, None)
+    assert call(good, None) == INVALID
+    bad = _lib.PinnAdamState(None, fake, 1, 1e-3, 0.9, 0.999, 1e-8, 0, 0, None, None)
+    assert call(good, C.byref(bad)) == INVALID
+    bad = _lib.PinnAdamState(fake, fake, 0, 1e-3, 0.9, 0.999, 1e-8, 0, 0, None, None)       # steps count from 1
+    assert call(good, C.byref(bad)) == INVALID
+    assert call(good, C.byref(st), n_cols=0, n_res=50) == INVALID and "n_res must equal N" in err(lib)
+    bad = _lib.PinnAdamState(fake, fake, 1, 1e-3, 0.9, 0.999, 1e-8, 0, 3, None, None)         # loss rows without buffers
+    assert call(good, C.byref(bad)) == INVALID and "loss_rows" in err(lib)
+    # the wide engine (and the generic one) are refused, nothing launched
+    for desc in (NetDesc(3, 4, 12, 256, (0, 1, 2)), NetDesc(3, 4, 8, 64, (0, 1, 2), engine=1)):
+        assert call(desc, C.byref(st)) == UNSUPPORTED and "one-pass request on the fused engine" in err(lib)
+    lr = (C.c_double * 2)(1e-3, 1e-3)
+    args = (C.byref(good.c_struct()), C.byref(spec.c_struct()), fake, fake, 0, oc, fake, fake, fake, 100, 100, fake, fake, fake)
+    assert lib.pinn_adam_loop(*args, C.byref(st), 2, None, fake, 1 << 30, None) == INVALID
+    assert lib.pinn_adam_loop(*args, None, 2, lr, fake, 1 << 30, None) == INVALID
+    assert lib.pinn_adam_loop(*args, C.byref(st), 0, lr, fake, 1 << 30, None) == OK            # zero iterations: nothing to do
