@@ -166,19 +166,6 @@ __device__ __forceinline__ float tanh_bf(float x) {
 }
 
 
-// Workgroups that share an XCD (blockIdx.x % 8, observed dispatch: speed only) all start on the same weight slab;
-// `chain_stagger` delays each by its index inside the XCD times ~one GEMM step, so that at any time the XCD's CUs
-// ask its L2 for DIFFERENT slabs instead of queueing 32-deep on the same lines.
-#ifndef PINN_CHAIN_STAGGER
-#define PINN_CHAIN_STAGGER 24      // s_sleep(64) units of 64 clocks... x 64 cycles per workgroup index inside its XCD (0 = off)
-#endif
-__device__ __forceinline__ void chain_stagger() {
-  if (PINN_CHAIN_STAGGER > 0) {
-    const int k = (blockIdx.x >> 3) & 31;
-    for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(PINN_CHAIN_STAGGER);
-  }
-}
-
 // The weight ring of the two chain kernels.  Slabs are consumed in a fixed order (tile batch, layer, output tile);
 // `next` walks that order one slab ahead of the R - 1 in flight.  Everything is wave-uniform.
 template <int NTW, int SLAB, int R, bool DESCENDING, int NW = CHAIN_WAVES>
@@ -362,7 +349,6 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_fwd8(const ChainParams 
     for (int i = threadIdx.x; i < 16 * NTW; i += P8_THREADS) w0_lds[i] = f4{P.W0[i * 16], P.W0[i * 16 + 1], P.W0[i * 16 + 2], 0.f};
   }
   __syncthreads();
-  chain_stagger();
   // The ring.  A wave's vector-memory operations retire in issue order, so "slab g has landed" is a vmcnt wait for
   // at most the operations issued after its copies.  To make that number a compile-time constant of the step, every
   // step issues the same operations whatever the layer: QD copies (past the last slab: of slab 0 into a spare slot
@@ -590,7 +576,6 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_bwd(const ChainParam
   const int nh = P.L - 1;
   const int64_t n_tb = (P.n_tiles + CHAIN_WAVES - 1) / CHAIN_WAVES;
   const int64_t my_tb = (n_tb - blockIdx.x + gridDim.x - 1) / gridDim.x;
-  chain_stagger();
   SlabRing<NTW, SLAB, R, true> ring;               // slab order: layers nh-1 .. 0 (descending), tiles 0 .. NTW-1
   ring.init(P.WTf, P.w_plane, smem, nh, my_tb * nh * NTW, wave, lane);
   char* pf = smem + R * SLAB + wave * PF_BYTES;    // this wave's prefetch area
