@@ -279,9 +279,6 @@ __host__ __device__ constexpr int chain_pf_pieces(int NTW, int K1) {   // k-step
 constexpr int P8_WAVES = 8;
 constexpr int P8_THREADS = P8_WAVES * 64;
 
-__device__ __forceinline__ float dpp_ror8(float v) {      // lane i <- lane (i + 8) mod 16 of its row of 16
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
-}
 // two stores (each a pair of quantity blocks) per step until the NGS = NG * NS stores of a layer are out: all in the
 // first half of the layer, so that they are old — retired, or nearly — when the batch boundary drains the queue
 template <int NGS>
@@ -307,8 +304,6 @@ __device__ __forceinline__ float dpp_hi_from_lo(float v) {
 // multiplications with parf = (float)par — the vector ALU's issue port is shared with the MFMAs of the SIMD's other wave.
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 dpp2_hi_from_lo(f2 v) { return f2{dpp_hi_from_lo(v[0]), dpp_hi_from_lo(v[1])}; }
-__device__ __forceinline__ f2 dpp2_ror8(f2 v) { return f2{dpp_ror8(v[0]), dpp_ror8(v[1])}; }
-__device__ __forceinline__ f2 bf2f2(bf8 v, int j) { return f2{bf2f(v[j]), bf2f(v[j + 1])}; }   // elements j, j + 1 (j even: one dword)
 // Roles inside a step.  Waves w and w + 4 share a SIMD (dispatch order); run in lockstep they would both stall on
 // their weight copies, then both on their fragment reads, then fight over the matrix pipe.  So the two halves of
 // the workgroup order a step differently: waves 0-3 ("early") issue their copies and stores and run the
@@ -455,7 +450,7 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_fwd8(const ChainParams 
         constexpr int M = decltype(m_)::value, s = M / 2, h = M % 2;
         const f4 b4 = *reinterpret_cast<const f4*>(bl + 16 * M + 4 * q);
 #pragma unroll
-        for (int r = 0; r < 4; r += 2) {                        // two units at a time, packed fp32 (see p8_adjoint)
+        for (int r = 0; r < 4; r += 2) {                        // two units at a time, packed fp32
           const f2 x = f2{a[0][r], a[0][r + 1]};
           const f2 e2 = (x + f2{b4[r], b4[r + 1]}) * 2.885390081777927f;      // 2 log2(e) (x + b)
           const f2 ex = f2{__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])} + 1.f;
