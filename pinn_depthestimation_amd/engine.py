@@ -191,6 +191,7 @@ class Engine:
         (appended as the last argument), whatever device the calling thread has current: launch
         geometry (CU count) and the stream both belong to the device the tensors live on."""
         idx = self._index()
+        self._packed_tok = None      # any other call may re-pack the workspace from ITS params argument
         if torch.cuda.current_device() != idx:
             with torch.cuda.device(idx):
                 check(fn(*args, C.c_void_p(torch.cuda.current_stream(idx).cuda_stream)), what)

@@ -179,3 +179,23 @@ def test_trainer_with_and_without_the_folded_update_walks_the_same_trajectory(tm
     assert np.allclose(np.array(res[True][1])[:, 1:], np.array(res[False][1])[:, 1:], rtol=2e-6, atol=0.0)
     for k in res[False][2]:
         assert torch.equal(res[False][2][k], res[True][2][k]), k
+
+
+def test_packed_weights_are_not_trusted_after_another_call_on_the_engine():
+    """Between two folded iterations a forward pass with OTHER parameters re-packs the workspace: the next folded
+    iteration must pack again (it equals the classic path bit for bit only if it does)."""
+    desc, spec, flat0, X, T, scale, cscale, fid, n_res = _setup("ns8x64_res_only")
+    P = flat0.numel()
+    out = []
+    for folded in (False, True):
+        eng = Engine(desc)
+        th, m, v, grad = flat0.clone(), torch.zeros(P, device="cuda"), torch.zeros(P, device="cuda"), torch.zeros(P, device="cuda")
+        ts = torch.zeros(spec.n_terms, device="cuda")
+        for step in (1, 2, 3):
+            if folded:
+                assert eng.loss_grad_adam_step(spec, scale, th, X, X.shape[0], grad, m, v, step, 1e-3, term_sums=ts)
+                eng.forward(torch.zeros_like(th), X)            # someone else's parameters through the same engine
+            else:
+                grad.zero_(); eng.residual_loss_grad(spec, scale, th, X, grad, sums=ts); eng.adam_step(th, grad, m, v, step, 1e-3)
+        out.append(th)
+    assert torch.equal(out[0], out[1])
