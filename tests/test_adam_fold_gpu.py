@@ -199,3 +199,24 @@ def test_packed_weights_are_not_trusted_after_another_call_on_the_engine():
                 grad.zero_(); eng.residual_loss_grad(spec, scale, th, X, grad, sums=ts); eng.adam_step(th, grad, m, v, step, 1e-3)
         out.append(th)
     assert torch.equal(out[0], out[1])
+
+
+def test_runs_of_iterations_log_the_same_iterations_as_the_per_iteration_loop(tmp_path):
+    """log_every = 7 with a 16-row log ring and no checkpoints: train_adam enqueues runs that stop when the ring is full;
+    the logged iterations and their losses equal those of the classic per-iteration loop."""
+    rs = np.random.RandomState(6)
+    Xr = rs.rand(243, 3).astype(np.float32) * 2 - 1
+    res = {}
+    for fold in (False, True):
+        torch.manual_seed(99)
+        tr = PINN(None, None, Xr, _cfg(120, ()), log_every=7, checkpoint_every=0, log_flush_every=16, fold_adam=fold)
+        if fold:
+            tr.train_adam(120)
+        else:
+            for _ in range(120):
+                tr.adam_step()
+        res[fold] = (tr.dnn.flat_params().clone(), list(tr.history), tr._folded_iters)
+    assert res[True][2] == 120 and res[False][2] == 0
+    assert torch.equal(res[False][0], res[True][0])
+    assert [r[0] for r in res[True][1]] == [r[0] for r in res[False][1]] == [i for i in range(1, 121) if i % 7 == 0]
+    assert np.allclose(np.array(res[True][1])[:, 1:], np.array(res[False][1])[:, 1:], rtol=2e-6, atol=0.0)
