@@ -48,6 +48,10 @@ constexpr int CHAIN_RING = 6;              // weight slabs in the LDS ring of th
 #define PINN_CHAIN_RING_FWD 6
 #endif
 constexpr int CHAIN_RING_FWD = PINN_CHAIN_RING_FWD;   // ... of the forward chain
+#ifndef PINN_FWD8_PREFETCH
+#define PINN_FWD8_PREFETCH 4
+#endif
+constexpr int FWD8_PREFETCH = PINN_FWD8_PREFETCH;     // k-steps of the next slab read before the barrier (0: off)
 // Weight precision of the REVERSE chain.  Measured on the reference's 12 x 256 golden (G10): rounding the weights to
 // bf16 in the FORWARD pass moves the gradient by 1.2e-1 (the loss is evaluated at a shifted point of a stiff
 // surface) — the forward chain always multiplies by hi + lo.  Rounding them in the reverse pass alone is a random,
@@ -360,6 +364,26 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_fwd8(const ChainParams 
     }
   };
   for (int g0 = 0; g0 < R - 1; ++g0) issue();
+  // Fragment prefetch across the barrier.  The barrier of step g certifies slab g + 1 (not g), one slab less in flight:
+  // a wave can then read the first PFN k-steps of the NEXT slab right after its own MFMAs, and opens its next step on
+  // fragments that are already in registers instead of an LDS round trip behind the barrier.
+  constexpr int PFN = FWD8_PREFETCH;
+  bf8 pfh[PFN > 0 ? PFN : 1], pfl[PFN > 0 ? PFN : 1];
+  auto prefetch = [&]() {
+    if constexpr (PFN > 0) {
+      const char* sl = ring.consume_ptr();
+#pragma unroll
+      for (int s = 0; s < PFN; ++s) {
+        pfh[s] = *reinterpret_cast<const bf8*>(sl + s * 1024);
+        pfl[s] = *reinterpret_cast<const bf8*>(sl + (NS + s) * 1024);
+      }
+    }
+  };
+  if constexpr (PFN > 0) {
+    wait_vm<(R - 2) * QD>();            // slab 0 of the R - 1 just requested
+    __builtin_amdgcn_s_barrier();
+    prefetch();
+  }
   CHAIN_DIAG_BEGIN;
   constexpr int TILE_BYTES = K1 * NS * 1024;
   bf8 bj[NG][NS], bn[NG][NS], bx[NG][NS];
@@ -482,10 +506,12 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_fwd8(const ChainParams 
           // younger than this step's slab: the copies of R - 2 slabs, the stores of the last R - 1 steps and, in
           // the first R - 1 steps of a layer, what was issued at its start: the a_L stores of the previous batch
           // (first layer), the a_1 loads of the next one (last layer)
-          constexpr int N = (R - 2) * QD + p8_younger_stores<NST, NTW, R, MT, true, true>();
+          // (with the fragment prefetch the target is the NEXT step's slab, issued R - 2 steps ago)
+          constexpr int RB = PFN > 0 ? R - 1 : R;
+          constexpr int N = (RB - 2) * QD + p8_younger_stores<NST, NTW, RB, MT, true, true>();
           constexpr int NLD = FOLD ? 3 : NST;          // loads issued at the start of the last layer
           static_assert(N + NST + NLD <= 63, "vmcnt range");
-          if (MT < R - 1 && (l == 1 || l == nh)) {
+          if (MT < RB - 1 && (l == 1 || l == nh)) {
             if (l == 1 && l == nh) wait_vm<N + NST + NLD>();
             else if (l == 1) wait_vm<N + NST>();
             else wait_vm<N + NLD>();
@@ -506,8 +532,8 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_fwd8(const ChainParams 
         const char* sl = ring.consume_ptr();
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-          const bf8 ahi = *reinterpret_cast<const bf8*>(sl + s * 1024);
-          const bf8 alo = *reinterpret_cast<const bf8*>(sl + (NS + s) * 1024);
+          const bf8 ahi = s < PFN ? pfh[s < PFN ? s : 0] : *reinterpret_cast<const bf8*>(sl + s * 1024);
+          const bf8 alo = s < PFN ? pfl[s < PFN ? s : 0] : *reinterpret_cast<const bf8*>(sl + (NS + s) * 1024);
 #pragma unroll
           for (int G = 0; G < NG; ++G) {
             accc[G] = mfma32(ahi, bj[G][s], accc[G]);
@@ -515,6 +541,7 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_fwd8(const ChainParams 
           }
         }
         ring.consumed();
+        prefetch();
         CHAIN_STAMP(2);
         if (!early) {
           side(mt_);
