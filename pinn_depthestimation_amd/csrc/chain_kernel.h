@@ -48,6 +48,10 @@ constexpr int CHAIN_RING = 6;              // weight slabs in the LDS ring of th
 #define PINN_CHAIN_RING_FWD 6
 #endif
 constexpr int CHAIN_RING_FWD = PINN_CHAIN_RING_FWD;   // ... of the forward chain
+#ifndef PINN_BWD_PREFETCH
+#define PINN_BWD_PREFETCH 8
+#endif
+constexpr int BWD_PREFETCH = PINN_BWD_PREFETCH;       // k_chain_bwd: the same, inside a layer
 #ifndef PINN_FWD8_PREFETCH
 #define PINN_FWD8_PREFETCH 4
 #endif
@@ -199,10 +203,10 @@ struct SlabRing {
   // copies of the R - 2 younger slabs — plus the EXTRA jet stores this wave is known to have issued after
   // them (`extra_issued`; vmcnt retires in issue order, so every younger operation must be counted or the wait
   // is for too much) — are outstanding.  Near the end of the sequence fewer younger slabs exist: drain everything.
-  template <int EXTRA>
+  template <int EXTRA, int RB = R>     // RB = R - 1: the target is the NEXT step's slab (one slab less in flight)
   __device__ __forceinline__ void wait_landed(int64_t g, bool extra_issued) {
     constexpr int QDMA = SLAB / NW / 1024;
-    constexpr int N = (R - 2) * QDMA;
+    constexpr int N = (RB - 2) * QDMA;
     if (g + R - 1 > total) wait_vm<0>();           // (issue() has been skipping: fewer than R - 2 younger slabs)
     else if (EXTRA > 0 && N + EXTRA <= 63 && extra_issued) wait_vm<(N + EXTRA <= 63 ? N + EXTRA : N)>();
     else wait_vm<N>();
@@ -583,6 +587,10 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_bwd(const ChainParam
   constexpr int SLAB = NS * (LO ? 2 : 1) * 1024;     // the hi pieces are the first NS planes of a packed slab
   constexpr int QD = SLAB / 4 / 1024;
   constexpr int R = CHAIN_RING;
+  // fragment prefetch across the barrier (see k_chain_fwd8): inside a layer the barrier of a step certifies the NEXT
+  // step's slab, whose first PFB k-steps are read right after this step's MFMAs
+  constexpr int PFB = BWD_PREFETCH < NS ? BWD_PREFETCH : NS;   // (all of them at width 256: 15.0 -> 14.0 ms; 2: 14.4, 4: 14.2)
+  constexpr int RB = PFB > 0 ? R - 1 : R;
   // the first PF k-step pieces of the NEXT adjoint phase's a_l are copied into LDS (two 1 KB LDS-DMA copies per GEMM
   // step from step 0) while this layer's GEMM runs: the phase then starts on data that is already on
   // chip and its remaining pieces stream into registers behind it.  (All of a_l does not fit: ring + 4 waves x 16 KB
@@ -696,6 +704,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_bwd(const ChainParam
       zero_tiles<NTW, K1>(acc);
       const bool pf_cur = live && l >= 2;          // a_l for the next phase (layer l - 1)
       const char* pf_src = reinterpret_cast<const char*>(P.A + (int64_t)(l - 1) * P.jet_stride + tbase);
+      bf8 pfh[PFB > 0 ? PFB : 1], pfl[PFB > 0 ? PFB : 1];
       static_for<0, NTW>([&](auto mt_) {
         constexpr int MT = decltype(mt_)::value;
         CHAIN_STAMP(2);
@@ -704,12 +713,12 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_bwd(const ChainParam
           // prefetch copy per step.  Steps before R - 1: slab g was requested before the adjoint phase, whose
           // load waits have retired it already (vmcnt retires in order): any count is safe there; later steps
           // count every younger operation exactly.
-          constexpr int E = chain_younger_stores<K1, NS, NTW, R, MT, true, false>();
-          constexpr int EP = chain_younger_prefetch<R, NPF>(MT);
-          static_assert((R - 2) * QD + E + EP <= 63, "vmcnt range");
-          if (live && pf_cur) ring.template wait_landed<E + EP>(g, true);
-          else if (live) ring.template wait_landed<E>(g, true);
-          else ring.template wait_landed<0>(g, false);
+          constexpr int E = chain_younger_stores<K1, NS, NTW, RB, MT, true, false>();
+          constexpr int EP = chain_younger_prefetch<RB, NPF>(MT);
+          static_assert((RB - 2) * QD + E + EP <= 63, "vmcnt range");
+          if (live && pf_cur) ring.template wait_landed<E + EP, RB>(g, true);
+          else if (live) ring.template wait_landed<E, RB>(g, true);
+          else ring.template wait_landed<0, RB>(g, false);
         }
         CHAIN_STAMP(0);
         __builtin_amdgcn_s_barrier();
@@ -732,16 +741,25 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void k_chain_bwd(const ChainParam
         const char* sl = ring.consume_ptr();
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-          const bf8 ahi = *reinterpret_cast<const bf8*>(sl + s * 1024);
+          constexpr bool havepf = PFB > 0 && MT > 0;
+          const bf8 ahi = (havepf && s < PFB) ? pfh[s < PFB ? s : 0] : *reinterpret_cast<const bf8*>(sl + s * 1024);
 #pragma unroll
           for (int c = 0; c < K1; ++c) acc[c][MT] = mfma32(ahi, zj[c][s], acc[c][MT]);
           if constexpr (LO) {
-            const bf8 alo = *reinterpret_cast<const bf8*>(sl + (NS + s) * 1024);
+            const bf8 alo = (havepf && s < PFB) ? pfl[s < PFB ? s : 0] : *reinterpret_cast<const bf8*>(sl + (NS + s) * 1024);
 #pragma unroll
             for (int c = 0; c < K1; ++c) acc[c][MT] = mfma32(alo, zj[c][s], acc[c][MT]);
           }
         }
         ring.consumed();
+        if constexpr (PFB > 0 && MT + 1 < NTW) {
+          const char* sn = ring.consume_ptr();
+#pragma unroll
+          for (int s = 0; s < PFB; ++s) {
+            pfh[s] = *reinterpret_cast<const bf8*>(sn + s * 1024);
+            if constexpr (LO) pfl[s] = *reinterpret_cast<const bf8*>(sn + (NS + s) * 1024);
+          }
+        }
         ++g;
       });
     }
