@@ -807,7 +807,9 @@ template <int NTW, int K1>
 __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_wgrad8(const ChainParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NS = NTW / 2;
-  constexpr int MTB = NTW / P8_WAVES;              // output tiles per wave: 2 (W = 256) or 1 (W = 128)
+  // a wave owns MTB row tiles x NCB column tiles of dW_l (row group wave >> 1, column half wave & 1): 4 x 8 at width 256
+  // (12 operands per 32 MFMAs; as 2 x 16 it was 18, and the transposed reads are a measurable part of the unit)
+  constexpr int MTB = NTW / 4, NCB = NTW / 2;
   constexpr int KU = (K1 + 1) / 2;                 // k-steps per tile
   constexpr int HALF = 2 * NS * 1024;              // bytes of one operand's two quantities
   constexpr int UNIT = 2 * HALF;                   // [zbar c0 | zbar c1 | a c0 | a c1] x NS blocks
@@ -840,13 +842,13 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_wgrad8(const ChainParam
       dma_1k<PINN_CHAIN_JET_LD_AUX>(src, dst + jj * 1024, lane);
     }
   };
-  f4 dw[MTB][NTW];
+  f4 dw[MTB][NCB];
   float bs[MTB];
 #pragma unroll
   for (int m = 0; m < MTB; ++m) {
     bs[m] = 0.f;
 #pragma unroll
-    for (int n = 0; n < NTW; ++n) dw[m][n] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NCB; ++n) dw[m][n] = f4{0.f, 0.f, 0.f, 0.f};
   }
   for (int u0 = 0; u0 < RU - 1; ++u0) issue_unit(u0);
   // address of this lane's transposed-read element inside a quantity's NS-block region:
@@ -870,11 +872,11 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_wgrad8(const ChainParam
     bf8 za[MTB];
 #pragma unroll
     for (int m = 0; m < MTB; ++m) {
-      const int MT = wave * MTB + m;
+      const int MT = (wave >> 1) * MTB + m;
       bf8 v = tr_operand(zb + (MT >> 1) * 1024 + (MT & 1) * 8);
       if (!qlive) v = bf8{0, 0, 0, 0, 0, 0, 0, 0};
       za[m] = v;
-      if (ku == 0 && qk < 2) {                     // bias gradient: sum over points of zbar's value quantity
+      if (ku == 0 && qk < 2 && (wave & 1) == 0) {                     // bias gradient: sum over points of zbar's value quantity
         float sacc = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) sacc += bf2f(v[j]);
@@ -882,8 +884,9 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_wgrad8(const ChainParam
       }
     }
 #pragma unroll
-    for (int n = 0; n < NTW; ++n) {
-      const bf8 bb = tr_operand(ab + (n >> 1) * 1024 + (n & 1) * 8);
+    for (int n = 0; n < NCB; ++n) {
+      const int NT = (wave & 1) * NCB + n;
+      const bf8 bb = tr_operand(ab + (NT >> 1) * 1024 + (NT & 1) * 8);
 #pragma unroll
       for (int m = 0; m < MTB; ++m) dw[m][n] = mfma32(za[m], bb, dw[m][n]);
     }
@@ -897,19 +900,19 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_wgrad8(const ChainParam
   float* dbl = dWl + (int64_t)P.W * P.W;
 #pragma unroll
   for (int m = 0; m < MTB; ++m) {
-    const int MT = wave * MTB + m;
+    const int MT = (wave >> 1) * MTB + m;
 #pragma unroll
-    for (int n = 0; n < NTW; ++n)
+    for (int n = 0; n < NCB; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = 16 * MT + 4 * qk + r, col = 16 * n + i16;
+        const int row = 16 * MT + 4 * qk + r, col = 16 * ((wave & 1) * NCB + n) + i16;
         if (row < P.W && col < P.W)
           __hip_atomic_fetch_add(dWl + (int64_t)row * P.W + col, dw[m][n][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     float tsum = bs[m];                            // lanes (i16, qk = 0, 1) hold points 0-7 / 8-15 of unit 16 MT + i16
     tsum += __shfl_xor(tsum, 16, 64);
     const int row = 16 * MT + i16;
-    if (qk == 0 && row < P.W) __hip_atomic_fetch_add(dbl + row, tsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (qk == 0 && (wave & 1) == 0 && row < P.W) __hip_atomic_fetch_add(dbl + row, tsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
