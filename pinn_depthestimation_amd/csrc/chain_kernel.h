@@ -1070,10 +1070,89 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_chain_last_bwd(const Chain
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Output layer, forward: out = W_L a_L + b_L on the bf16 a_L (chain layout) with v_mfma_f32_16x16x32_bf16 — W_L split
+// hi + lo like the hidden weights — then the loss epilogue of the fused / wide kernels (outputs, residual, fidelity
+// terms, loss partial sums, output adjoint G).  The wide engine's kernel for this converted a_L to fp32 and ran 256
+// fp32 MFMAs per tile: 8 k cycles of matrix pipe and ~3 k of conversions that the fp32 MFMA cannot overlap, next to an
+// epilogue of ~10 k (0.87 ms per 2^20 points); here the product is 64 bf16 MFMAs on operands that need no conversion.
+constexpr int LAST_PADS = 4;        // LDS pads per wave for the epilogue's scatter (it uses at most two)
+template <int NTW, int K1, bool GRAD>
+__global__ __launch_bounds__(WIDE_THREADS, 2) void k_chain_last_fwd(const FusedParams P, const WideLayer Lp) {
+  extern __shared__ __attribute__((aligned(16))) char smem_[];
+  float* smem = reinterpret_cast<float*>(smem_);
+  constexpr int NS = NTW / 2;
+  constexpr int TILE_BYTES = K1 * NS * 1024;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = lane & 15, q = lane >> 4;
+  bf8* wf = reinterpret_cast<bf8*>(smem);                                  // [hi | lo][k-step s][lane]: A fragments of W_L
+  float* tb = smem + 2 * NS * 64 * 4 + wave * (LAST_PADS * TB_FLOATS);
+  float* lsum = smem + 2 * NS * 64 * 4 + WIDE_WAVES * LAST_PADS * TB_FLOATS;
+  for (int i = threadIdx.x; i < NS * 64; i += WIDE_THREADS) {
+    const int s = i >> 6, ln = i & 63, o = ln & 15, qk = ln >> 4;
+    bf8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float w = Lp.W[o * (16 * NTW) + 32 * s + 16 * (j >> 2) + 4 * qk + (j & 3)];   // padded row-major [16][WP]
+      hi[j] = (__bf16)w;
+      lo[j] = (__bf16)(w - (float)hi[j]);
+    }
+    wf[i] = hi; wf[NS * 64 + i] = lo;
+  }
+  __syncthreads();
+  float sums[MAX_SUMS];
+#pragma unroll
+  for (int j = 0; j < MAX_SUMS; ++j) sums[j] = 0.f;
+  ScatterMap<K1> sm, sm_mse;
+  build_scatter_maps<K1>(P, q, sm, sm_mse);
+  const unsigned lpos = (4u * p + q) * 16u;
+  const unsigned short* AL = reinterpret_cast<const unsigned short*>(Lp.in_act);
+  const int gw = blockIdx.x * WIDE_WAVES + wave, nw = gridDim.x * WIDE_WAVES;
+  for (int64_t t = gw; t < Lp.n_tiles; t += nw) {
+    const int64_t pt = (Lp.tile0 + t) * 16 + p;
+    const bool valid = pt < P.N;
+    const int64_t ptc = valid ? pt : P.N - 1;
+    const __amdgpu_buffer_rsrc_t ar = jet_rsrc(AL + uniform64(t) * (K1 * NS * 512), TILE_BYTES);
+    f4 acc[K1][1];
+    init_bias<1, K1>(Lp.b, acc, q);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const bf8 whi = wf[s * 64 + lane], wlo = wf[(NS + s) * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < K1; ++c) {
+        const bf8 b = ld_blk(ar, lpos, (c * NS + s) * 1024);
+        acc[c][0] = mfma32(whi, b, acc[c][0]);
+        acc[c][0] = mfma32(wlo, b, acc[c][0]);
+      }
+    }
+    f4 G[K1][1];
+    loss_epilogue<K1, GRAD>(P, acc, G, sums, sm, sm_mse, tb, pt, ptc, valid, p, q);
+    if constexpr (GRAD) {
+#pragma unroll
+      for (int c = 0; c < K1; ++c) *reinterpret_cast<f4*>(Lp.g_out + ((t * K1 + c) * 1 + 0) * 256 + lane * 4) = G[c][0];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < MAX_SUMS; ++j) {
+    float v = sums[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) lsum[wave * MAX_SUMS + j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < MAX_SUMS) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < WIDE_WAVES; ++w) v += lsum[w * MAX_SUMS + threadIdx.x];
+    P.wg_sums[((int64_t)Lp.sums_slot + blockIdx.x) * MAX_SUMS + threadIdx.x] = v;
+  }
+}
+
 template <int NTW> int launch_chain_fwd8(int K1, bool fold_first, const ChainParams& P, int grid, hipStream_t s);
 template <int NTW> int launch_chain_bwd(int K1, const ChainParams& P, int grid, hipStream_t s);
 template <int NTW> int launch_chain_wgrad8(int K1, const ChainParams& P, int grid, hipStream_t s);
 template <int NTW> int launch_chain_first_bwd(int K1, const ChainParams& P, int grid, hipStream_t s);
 template <int NTW> int launch_chain_last_bwd(int K1, const ChainParams& P, int grid, hipStream_t s);
+template <int NTW> int launch_chain_last_fwd(int K1, bool grad, const FusedParams& P, const WideLayer& Lp, int grid, hipStream_t s);
 
 }  // namespace pinn

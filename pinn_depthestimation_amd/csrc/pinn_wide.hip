@@ -26,6 +26,9 @@ int64_t chain_plane_bytes(int nh, int NTW) {
 
 int cus() { return device_cu_count(); }
 
+// bf16 mode's output-layer kernel (k_chain_last_fwd: three waves per SIMD fit) runs up to three workgroups per CU, each
+// with its own row of loss partial sums
+constexpr int SUM_ROWS_PER_CU = 3;
 constexpr int64_t ACT_BUDGET_BYTES = (int64_t)6 << 30;   // activation workspace per chunk (fp32 mode)
 // bf16 mode (chain kernels): 2L + 1 bf16 jets per chunk, and the weight-gradient kernel flushes its registers
 // once per chunk and workgroup — chunks are as large as a 288 GB part comfortably allows
@@ -78,7 +81,7 @@ WLayout wlayout(const Net& n, const WGeo& g, int64_t N) {
     else w.jG1 = w.jGL;                                  // no hidden matrix: abar_1 is abar_L
   }
   w.gout = off; off += al256(w.chunk_tiles * K1 * 256 * 4);
-  w.sums = off; off += al256(w.n_chunks * w.grid * MAX_SUMS * 4);
+  w.sums = off; off += al256(w.n_chunks * SUM_ROWS_PER_CU * w.grid * MAX_SUMS * 4);   // one row of loss partials per workgroup
   w.total = off;
   return w;
 }
@@ -217,10 +220,10 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
     Lp.tile0 = ch * w.chunk_tiles;
     Lp.n_tiles = total_tiles - Lp.tile0 < w.chunk_tiles ? total_tiles - Lp.tile0 : w.chunk_tiles;
     if (Lp.n_tiles <= 0) break;
-    Lp.sums_slot = (int)(ch * w.grid);
+    Lp.sums_slot = (int)(ch * SUM_ROWS_PER_CU * w.grid);
     const int grid = (int)((Lp.n_tiles + WIDE_WAVES - 1) / WIDE_WAVES < w.grid ? (Lp.n_tiles + WIDE_WAVES - 1) / WIDE_WAVES : w.grid);
     // zero this chunk's rows of the partial-sum table (a smaller grid leaves rows untouched)
-    if (hipMemsetAsync(P.wg_sums + (int64_t)Lp.sums_slot * MAX_SUMS, 0, (size_t)w.grid * MAX_SUMS * 4, s) != hipSuccess) {
+    if (hipMemsetAsync(P.wg_sums + (int64_t)Lp.sums_slot * MAX_SUMS, 0, (size_t)SUM_ROWS_PER_CU * w.grid * MAX_SUMS * 4, s) != hipSuccess) {
       set_error("hipMemsetAsync failed"); return PINN_ERR_LAUNCH;
     }
     if (chain) {
@@ -251,7 +254,11 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
 #endif
       if (nh > 0) { rc = launch_chain_fwd8<NTW>(K1, fold_first, C, cgrid, s); if (rc) break; }
       Lp.W = Wp + woff(L); Lp.b = Bp + L * g.WP; Lp.in_act = jetA(L); Lp.out_act = nullptr; Lp.g_out = gout;
-      rc = launch_wide_fwd<NTW>(2, K1, prec, grad, P, Lp, grid, s); if (rc) break;
+      {
+        const int64_t want = (Lp.n_tiles + WIDE_WAVES - 1) / WIDE_WAVES;
+        const int g3 = (int)(want < (int64_t)SUM_ROWS_PER_CU * w.grid ? want : (int64_t)SUM_ROWS_PER_CU * w.grid);
+        rc = launch_chain_last_fwd<NTW>(K1, grad, P, Lp, g3, s); if (rc) break;
+      }
 #ifdef PINN_CHAIN_DIAG
       if (!grad && nh > 0) {
         unsigned long long h[8];
@@ -365,10 +372,10 @@ int run_w(const Net& n, const WGeo& g, bool grad, const LossReq* rq, const float
   if (rq) {
     if (P.loss_kind & 1)
       hipLaunchKernelGGL(k_wide_reduce_sums, dim3(rq->n_terms), dim3(256), 0, s, (const float*)P.wg_sums,
-                         (int64_t)w.n_chunks * w.grid, 0, rq->n_terms, rq->sums);
+                         (int64_t)w.n_chunks * SUM_ROWS_PER_CU * w.grid, 0, rq->n_terms, rq->sums);
     if (P.loss_kind & 2)
       hipLaunchKernelGGL(k_wide_reduce_sums, dim3(rq->n_cols), dim3(256), 0, s, (const float*)P.wg_sums,
-                         (int64_t)w.n_chunks * w.grid, MSE_SUM0, rq->n_cols, rq->mse_sums);
+                         (int64_t)w.n_chunks * SUM_ROWS_PER_CU * w.grid, MSE_SUM0, rq->n_cols, rq->mse_sums);
   }
   return check_launch("wide reductions");
 }
