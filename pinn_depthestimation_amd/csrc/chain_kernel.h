@@ -14,6 +14,9 @@
 //                  streams zbar_l / a_l tiles through an LDS ring by LDS-DMA and takes the MFMA operands
 //                  out of it with ds_read_b64_tr_b16 (the hardware transpose: contraction over points).  Eight waves.
 //
+//   k_chain_first_bwd / k_chain_last_fwd / k_chain_last_bwd: the thin first (d_in <= 3) and last (d_out <= 4) layers as
+//                  streaming kernels on the same jets (the first layer's forward is part of k_chain_fwd8).
+//
 // HBM traffic per point and hidden layer: 2 KB (a written) + 2 + 2 (a, zbar in the reverse chain) + 4 (weight
 // gradient) = 10 KB, against 16 KB for one launch per layer; weights come from L2 once per workgroup and layer.
 //
