@@ -66,6 +66,8 @@ extern "C" {
  * environment variables and keeps no mutable state that changes results. */
 #define PINN_ENGINE_FUSED_TILE 4  /* one wave per 16-point tile (the large-N kernel) */
 #define PINN_ENGINE_FUSED_COOP 5  /* four waves per tile (small point sets; padded hidden width 64 only) */
+#define PINN_ENGINE_FUSED_BATCH 6 /* layer-major batches of 8 tiles per wave (narrow nets, hidden width <= 32, gradient
+                                   * passes; AUTO picks it from ~1.3e5 points; other requests fall back to _TILE) */
 
 /* GEMM operand precision.  Everything outside the MFMAs (tanh, residual, adjoints, gradient
  * accumulation, Adam) is fp32 in both modes. */

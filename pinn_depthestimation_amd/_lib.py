@@ -15,7 +15,7 @@ PINN_MAX_ROLES = 8
 
 ACT_TANH, ACT_LEAKY_RELU = 0, 1
 ENGINE_AUTO, ENGINE_GENERIC, ENGINE_FUSED, ENGINE_WIDE = 0, 1, 2, 3
-ENGINE_FUSED_TILE, ENGINE_FUSED_COOP = 4, 5     # sub-values of ENGINE_FUSED: force one of its kernels (pinn_hip.h)
+ENGINE_FUSED_TILE, ENGINE_FUSED_COOP, ENGINE_FUSED_BATCH = 4, 5, 6     # sub-values of ENGINE_FUSED: force one of its kernels (pinn_hip.h)
 ABI_VERSION = 3
 PREC_F32, PREC_BF16 = 0, 1
 

@@ -51,6 +51,14 @@ constexpr int CHAIN_RING = 6;              // weight slabs in the LDS ring of th
 #define PINN_CHAIN_RING_FWD 6
 #endif
 constexpr int CHAIN_RING_FWD = PINN_CHAIN_RING_FWD;   // ... of the forward chain
+// dynamic LDS of k_chain_fwd8 at padded width 16*ntw: ring + one spare slot (the ring's dummy copies) + every layer's
+// bias + (folded first layer) 16 B of W_0 per unit.  ONE formula for the launcher and for wide_supports(): the depth
+// limit of bf16 mode is whatever still fits the CU's 160 KB (L <= 43 at width 256, far more at width 128).
+constexpr size_t CHAIN_LDS_LIMIT = 160 * 1024;
+__host__ __device__ constexpr size_t chain_fwd8_lds_bytes(int ntw, int L, bool fold_first) {
+  return (size_t)CHAIN_RING_FWD * (ntw / 2) * 2 * 1024 + (size_t)ntw * 1024 + (size_t)(L + 1) * 16 * ntw * 4 +
+         (fold_first ? (size_t)16 * ntw * 16 : 0);
+}
 #ifndef PINN_BWD_PREFETCH
 #define PINN_BWD_PREFETCH 8
 #endif

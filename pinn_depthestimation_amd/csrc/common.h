@@ -11,10 +11,10 @@ namespace pinn {
 void set_error(const char* fmt, ...);
 
 // layer geometry helpers: layers = [d_in] + [width]*n_hidden + [d_out] (train.py:56)
-constexpr int FUSED_KERNEL_AUTO = 0, FUSED_KERNEL_TILE = 1, FUSED_KERNEL_COOP = 2;
+constexpr int FUSED_KERNEL_AUTO = 0, FUSED_KERNEL_TILE = 1, FUSED_KERNEL_COOP = 2, FUSED_KERNEL_BATCH = 3;
 struct Net {
   int d_in, d_out, L /*hidden layers*/, W, k, K1, act, prec;
-  int fused_kernel;  // FUSED_KERNEL_*: which fused kernel desc.engine asked for (PINN_ENGINE_FUSED_TILE / _COOP)
+  int fused_kernel;  // FUSED_KERNEL_*: which fused kernel desc.engine asked for (PINN_ENGINE_FUSED_TILE / _COOP / _BATCH)
   float drop_p;      // nn.Dropout rate in training mode (dnn.py:38), 0 = off
   uint32_t drop_seed, drop_thresh;   // keep unit iff dropout_bits(...) >= drop_thresh (= p * 2^32)
   int dir_col[PINN_MAX_DIRS];

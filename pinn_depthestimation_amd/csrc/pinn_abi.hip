@@ -74,9 +74,10 @@ int make_net(const pinn_desc* d, Net* n) {
     set_error("invalid precision %d", d->precision); return PINN_ERR_INVALID;
   }
   n->prec = d->precision;
-  if (d->engine < PINN_ENGINE_AUTO || d->engine > PINN_ENGINE_FUSED_COOP) { set_error("invalid engine %d", d->engine); return PINN_ERR_INVALID; }
+  if (d->engine < PINN_ENGINE_AUTO || d->engine > PINN_ENGINE_FUSED_BATCH) { set_error("invalid engine %d", d->engine); return PINN_ERR_INVALID; }
   n->fused_kernel = d->engine == PINN_ENGINE_FUSED_TILE ? FUSED_KERNEL_TILE
-                  : d->engine == PINN_ENGINE_FUSED_COOP ? FUSED_KERNEL_COOP : FUSED_KERNEL_AUTO;
+                  : d->engine == PINN_ENGINE_FUSED_COOP ? FUSED_KERNEL_COOP
+                  : d->engine == PINN_ENGINE_FUSED_BATCH ? FUSED_KERNEL_BATCH : FUSED_KERNEL_AUTO;
   if (!(d->dropout_p >= 0.f && d->dropout_p < 1.f)) { set_error("dropout_p=%g outside [0, 1)", (double)d->dropout_p); return PINN_ERR_INVALID; }
   n->drop_p = d->dropout_p; n->drop_seed = d->dropout_seed; n->drop_thresh = dropout_threshold(d->dropout_p);
   if (n->drop_p > 0.f && n->drop_thresh == 0) n->drop_thresh = 1;   // (0 means "off" in the kernels)
@@ -93,7 +94,7 @@ int make_net(const pinn_desc* d, Net* n) {
 // 1 = generic, 2 = fused, 3 = wide
 static int pick_engine(const pinn_desc* d, const Net& n, bool want_grad, int* rc) {
   *rc = PINN_OK;
-  const int asked = (d->engine == PINN_ENGINE_FUSED_TILE || d->engine == PINN_ENGINE_FUSED_COOP) ? PINN_ENGINE_FUSED : d->engine;
+  const int asked = (d->engine == PINN_ENGINE_FUSED_TILE || d->engine == PINN_ENGINE_FUSED_COOP || d->engine == PINN_ENGINE_FUSED_BATCH) ? PINN_ENGINE_FUSED : d->engine;
   if (n.drop_p > 0.f) {     // training-mode dropout lives in the generic engine's kernels
     if (asked != PINN_ENGINE_AUTO && asked != PINN_ENGINE_GENERIC) {
       set_error("dropout_p > 0 runs on the generic engine (engine AUTO or GENERIC), not on engine %d", d->engine);

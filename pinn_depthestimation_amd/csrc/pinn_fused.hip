@@ -2,6 +2,7 @@
 // launch geometry, cross-workgroup reductions.  Kernel: fused_kernel.h.
 #include <type_traits>
 #include "fused_coop_kernel.h"
+#include "fused_batch_kernel.h"
 
 namespace pinn {
 
@@ -45,6 +46,27 @@ bool use_coop(const Net& n, const Geo& g, bool grad, int64_t N) {
   return (N + 15) / 16 <= (int64_t)cu_count();
 }
 
+// Batch kernel (fused_batch_kernel.h): narrow networks, gradient passes, enough tiles that every wave of the chip
+// gets at least one full batch of FUSED_BATCH_T tiles.  desc.engine = PINN_ENGINE_FUSED_BATCH forces it at any N
+// (ragged batches are handled: tiles past the end are computed on a clamped point and contribute nothing).
+bool batch_supported(const Net& n, const Geo& g) {
+  return g.WP <= 32 && n.L >= 1 && n.L + 1 <= MAX_LOCKS && fused_batch_has_kernel(g.WP, n.W, n.d_in, n.K1, n.act);
+}
+bool use_batch(const Net& n, const Geo& g, bool grad, int64_t N) {
+  if (!grad || !batch_supported(n, g)) return false;
+  if (n.fused_kernel == FUSED_KERNEL_BATCH) return true;
+  if (n.fused_kernel != FUSED_KERNEL_AUTO) return false;
+  return (N + 15) / 16 >= (int64_t)cu_count() * BATCH_WAVES * batch_tiles(g.WP, n.K1) * FUSED_BATCH_OCC;
+}
+int64_t batch_lds_fixed_bytes(int WP, int K1) { return (int64_t)(BATCH_WAVES * batch_pads(WP, K1) * TB_FLOATS + BATCH_WAVES * MAX_SUMS) * 4; }
+int batch_ks(const Net& n) { return n.W <= 12 ? 3 : (n.W <= 16 ? 4 : (n.W <= 20 ? 5 : 8)); }   // k-steps of the kernel instance
+int batch_grid(int64_t n_tiles, int T) {
+  const int64_t nb = (n_tiles + T - 1) / T;
+  const int64_t want = (nb + BATCH_WAVES - 1) / BATCH_WAVES;
+  const int64_t cap = (int64_t)cu_count() * FUSED_BATCH_OCC;
+  return (int)(want < 1 ? 1 : (want < cap ? want : cap));
+}
+
 int grid_for(int64_t n_tiles, bool one_per_cu, int per_cu = 2) {
   int64_t want = (n_tiles + FUSED_WAVES - 1) / FUSED_WAVES;
   int64_t cap = (int64_t)cu_count() * (one_per_cu ? 1 : per_cu);
@@ -71,7 +93,17 @@ WsLayout ws_layout(const Net& n, const Geo& g, int64_t N) {
   w.wp = off; off += al((int64_t)g.PW * 4);
   w.wtp = off; off += al((int64_t)g.PW * 4);
   w.bp = off; off += al((int64_t)g.PB * 4);
-  w.scratch = off; off += al((int64_t)w.max_grid * FUSED_WAVES * n.L * g.slot_floats_k4 * 4);
+  int64_t scratch_bytes = (int64_t)w.max_grid * FUSED_WAVES * n.L * g.slot_floats_k4 * 4;
+  if (batch_supported(n, g)) {   // the batch kernel's slots: T tiles x (L - 1) layers x K1 <= 4 x KS x 64 floats per wave
+    int64_t b = 0;      // (one workspace serves the K1 = 3 and K1 = 4 instances: the larger of the two)
+    for (int k1 = 3; k1 <= 4; ++k1) {
+      const int T = batch_tiles(g.WP, k1);
+      const int64_t bk = (int64_t)batch_grid(n_tiles, T) * BATCH_WAVES * T * (n.L > 1 ? n.L - 1 : 1) * k1 * batch_ks(n) * 64 * 4;
+      if (bk > b) b = bk;
+    }
+    if (b > scratch_bytes) scratch_bytes = b;
+  }
+  w.scratch = off; off += al(scratch_bytes);
   w.wg_sums = off; off += al((int64_t)w.max_grid * MAX_SUMS * 4);
   const int64_t copies = w.max_grid;   // one (padded) gradient copy per workgroup, in LDS or — too large for it — here
   w.wg_grads = off; off += al(copies * g.PP * 4);
@@ -79,9 +111,14 @@ WsLayout ws_layout(const Net& n, const Geo& g, int64_t N) {
   return w;
 }
 
+// Which real unit sits at padded index j.  perm = 0: j itself.  perm = 1 (k_fused_batch, fused_batch_kernel.h): hidden
+// units and network inputs in k-step-major order, j <-> 16*(j/16) + perm16(j%16) (an involution, so the same formula
+// maps a real unit to its padded index); network outputs always stay in natural order.
+__host__ __device__ inline int unit_at(int j, bool permuted) { return permuted ? (j & ~15) + perm16(j & 15) : j; }
+
 // flat torch-layout parameters -> padded row-major W, padded transposed W, padded bias
 __global__ void k_pack(Net n, int WP, const float* __restrict__ params, float* __restrict__ Wp,
-                       float* __restrict__ WTp, float* __restrict__ Bp, int PW, int PB) {
+                       float* __restrict__ WTp, float* __restrict__ Bp, int PW, int PB, int perm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < PW) {
     // which layer block does padded index i fall in?
@@ -96,17 +133,18 @@ __global__ void k_pack(Net n, int WP, const float* __restrict__ params, float* _
     const int in_d = n.in_dim(l), out_d = n.out_dim(l);
     const int base = i - rem;
     {  // row-major [out][in]
-      const int o = rem / inP, c = rem % inP;
+      const int o = unit_at(rem / inP, perm && l < n.L), c = unit_at(rem % inP, perm);
       Wp[i] = (o < out_d && c < in_d) ? params[n.w_off(l) + (int64_t)o * in_d + c] : 0.f;
     }
     {  // transposed [in][out]
-      const int c = rem / outP, o = rem % outP;
+      const int c = unit_at(rem / outP, perm), o = unit_at(rem % outP, perm && l < n.L);
       WTp[base + rem] = (o < out_d && c < in_d) ? params[n.w_off(l) + (int64_t)o * in_d + c] : 0.f;
     }
   }
   if (i < PB) {
     int l = i / WP, o = i % WP;
     if (l >= n.L) { l = n.L; o = i - n.L * WP; }
+    o = unit_at(o, perm && l < n.L);
     Bp[i] = (o < n.out_dim(l)) ? params[n.b_off(l) + o] : 0.f;
   }
 }
@@ -128,8 +166,26 @@ __global__ void k_reduce_sums(const float* __restrict__ wg_sums, int grid, int c
 // grad_flat[real index] += sum over copies of the padded per-workgroup gradients.  64 parameters x
 // 4 copy groups per block; each thread adds its group's copies in index order and the 4 partial sums
 // are combined in a fixed order, so the result does not depend on scheduling.
+// a thread's share of the copies, added in index order; the loads of eight copies are issued together (one memory
+// round trip per eight instead of per copy: 59 -> 12 us on the 768 copies of the 10x10 net) — the ORDER of the
+// additions, and with it the result, is unchanged
+__device__ __forceinline__ float sum_copies(const float* __restrict__ wg, int64_t PP, int pidx, int c0, int c1) {
+  float s = 0.f;
+  int c = c0;
+  for (; c + 8 <= c1; c += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = wg[(int64_t)(c + j) * PP + pidx];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  for (; c < c1; ++c) s += wg[(int64_t)c * PP + pidx];
+  return s;
+}
+
 __global__ void k_reduce_grads(Net n, int WP, const float* __restrict__ wg, int copies, int PP, int PW,
-                               float* __restrict__ grad) {
+                               float* __restrict__ grad, int flags) {
+  const int perm = flags & 1, rmajor = flags >> 1;   // rmajor: [r][lane] inside a 16x16 block (bwgrad_flush, BSINK_ATOMIC)
   __shared__ float part[4][64];
   const int lane_p = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + lane_p;
@@ -143,12 +199,13 @@ __global__ void k_reduce_grads(Net n, int WP, const float* __restrict__ wg, int 
     const int wo = (l == 0) ? 0 : WP * 16 + (l - 1) * WP * WP;
     int pidx;
     if (r < (int64_t)in_d * out_d) {   // fragment-native block layout (fused_kernel.h, GradSink)
-      const int row = (int)(r / in_d), col = (int)(r % in_d), ntn = inP / 16;
-      pidx = wo + (((row >> 4) * ntn + (col >> 4)) * 64 + ((row & 15) >> 2) * 16 + (col & 15)) * 4 + (row & 3);
-    } else pidx = PW + l * WP + (int)(r - (int64_t)in_d * out_d);
+      const int row = unit_at((int)(r / in_d), perm && l < n.L), col = unit_at((int)(r % in_d), perm), ntn = inP / 16;
+      const int blk = (row >> 4) * ntn + (col >> 4), ln = ((row & 15) >> 2) * 16 + (col & 15);
+      pidx = rmajor ? wo + (blk * 4 + (row & 3)) * 64 + ln : wo + (blk * 64 + ln) * 4 + (row & 3);
+    } else pidx = PW + l * WP + unit_at((int)(r - (int64_t)in_d * out_d), perm && l < n.L);
     const int per = (copies + 3) / 4;
     const int c0 = grp * per, c1 = (c0 + per < copies) ? c0 + per : copies;
-    for (int c = c0; c < c1; ++c) s += wg[(int64_t)c * PP + pidx];
+    s = sum_copies(wg, PP, pidx, c0, c1);
   }
   part[grp][lane_p] = s;
   __syncthreads();
@@ -166,11 +223,18 @@ __global__ void k_finish_adam(Net n, int WP, const float* __restrict__ wg, int c
                               float* __restrict__ params, float* __restrict__ m, float* __restrict__ v,
                               float* __restrict__ Wp, float* __restrict__ WTp, float* __restrict__ Bp,
                               float w1, float b2, float w2, float eps, float step_size, float bc2_sqrt,
-                              int n_loss_rows, const float* __restrict__ loss_rows, float* __restrict__ losses) {
+                              int n_loss_rows, const float* __restrict__ loss_rows, float* __restrict__ losses,
+                              int row_cols, int flags) {
 #pragma clang fp contract(off)
+  const int perm = flags & 1, rmajor = flags >> 1;
   if (blockIdx.x == gridDim.x - 1) {          // loss sums: double, fixed order (k_reduce_sums)
     __shared__ double red[256];
-    __shared__ double ssum[2 * PINN_MAX_ROLES + 8];     // [col sums | term sums], for the optional weighted losses
+    // [col sums (row_cols of them) | term sums], for the optional weighted losses.  row_cols is the CALLER's column
+    // count — the stride of loss_rows (pinn_hip.h) — also when this pass carried no fidelity columns (n_cols = 0:
+    // a residual-only request with n_res == N): their sums are then zeros, not a shifted layout.
+    __shared__ double ssum[2 * PINN_MAX_ROLES + 8];
+    if (threadIdx.x < 2 * PINN_MAX_ROLES + 8) ssum[threadIdx.x] = 0.0;
+    __syncthreads();
     for (int j = 0; j < n_terms + n_cols; ++j) {
       const int t = j < n_terms ? j : MSE_SUM0 + (j - n_terms);
       double a = 0.0;
@@ -182,14 +246,14 @@ __global__ void k_finish_adam(Net n, int WP, const float* __restrict__ wg, int c
         __syncthreads();
       }
       if (threadIdx.x == 0) {
-        if (j < n_terms) { term_sums[j] = (float)red[0]; ssum[n_cols + j] = (double)(float)red[0]; }
+        if (j < n_terms) { term_sums[j] = (float)red[0]; ssum[row_cols + j] = (double)(float)red[0]; }
         else { col_sums[j - n_terms] = (float)red[0]; ssum[j - n_terms] = (double)(float)red[0]; }
       }
       __syncthreads();
     }
     if ((int)threadIdx.x < n_loss_rows) {
       double a = 0.0;
-      for (int j = 0; j < n_cols + n_terms; ++j) a += (double)loss_rows[threadIdx.x * (n_cols + n_terms) + j] * ssum[j];
+      for (int j = 0; j < row_cols + n_terms; ++j) a += (double)loss_rows[threadIdx.x * (row_cols + n_terms) + j] * ssum[j];
       losses[threadIdx.x] = (float)a;
     }
     return;
@@ -208,14 +272,15 @@ __global__ void k_finish_adam(Net n, int WP, const float* __restrict__ wg, int c
     wo = (l == 0) ? 0 : WP * 16 + (l - 1) * WP * WP;
     int pidx;
     is_w = r < (int64_t)in_d * out_d;
-    if (is_w) {   // fragment-native block layout (fused_kernel.h, GradSink)
-      row = (int)(r / in_d); col = (int)(r % in_d);
+    if (is_w) {   // fragment-native block layout (fused_kernel.h, GradSink); row / col: PADDED indices from here on
+      row = unit_at((int)(r / in_d), perm && l < n.L); col = unit_at((int)(r % in_d), perm);
       const int ntn = inP / 16;
-      pidx = wo + (((row >> 4) * ntn + (col >> 4)) * 64 + ((row & 15) >> 2) * 16 + (col & 15)) * 4 + (row & 3);
-    } else { row = (int)(r - (int64_t)in_d * out_d); pidx = PW + l * WP + row; }
+      const int blk = (row >> 4) * ntn + (col >> 4), ln = ((row & 15) >> 2) * 16 + (col & 15);
+      pidx = rmajor ? wo + (blk * 4 + (row & 3)) * 64 + ln : wo + (blk * 64 + ln) * 4 + (row & 3);
+    } else { row = unit_at((int)(r - (int64_t)in_d * out_d), perm && l < n.L); pidx = PW + l * WP + row; }
     const int per = (copies + 3) / 4;
     const int c0 = grp * per, c1 = (c0 + per < copies) ? c0 + per : copies;
-    for (int c = c0; c < c1; ++c) s += wg[(int64_t)c * PP + pidx];
+    s = sum_copies(wg, PP, pidx, c0, c1);
   }
   part[grp][lane_p] = s;
   __syncthreads();
@@ -279,12 +344,19 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
       for (int j = 0; j < PINN_MAX_ROLES; ++j) P.mse_col[j] = j < rq->n_cols ? rq->out_col[j] : -1;
     }
   }
-  const bool coop = use_coop(n, g, grad, N);
+  const bool batch = use_batch(n, g, grad, N);
+  const bool coop = !batch && use_coop(n, g, grad, N);
   if (coop) {
     P.acc_lds = grad ? 1 : 0;
     P.lds_acc_floats = grad ? g.PP : 0;
   }
-  const size_t lds = coop ? (size_t)coop_lds_bytes(n, g, grad) : (size_t)P.lds_acc_floats * 4 + (size_t)lds_fixed_bytes();
+  if (batch) {   // the batch kernel carves its own pads (batch_pads per wave); the gradient copy stays in LDS if it still fits
+    // a gradient copy per wave in LDS if four of them fit, else atomics into BATCH_ATOMIC_COPIES shared copies (bwgrad_flush)
+    P.acc_lds = ((int64_t)BATCH_WAVES * g.PP * 4 + batch_lds_fixed_bytes(g.WP, n.K1)) * FUSED_BATCH_OCC <= LDS_LIMIT ? 1 : 0;
+    P.lds_acc_floats = P.acc_lds ? BATCH_WAVES * g.PP : 0;
+  }
+  const size_t lds = batch ? (size_t)P.lds_acc_floats * 4 + (size_t)batch_lds_fixed_bytes(g.WP, n.K1)
+                   : coop ? (size_t)coop_lds_bytes(n, g, grad) : (size_t)P.lds_acc_floats * 4 + (size_t)lds_fixed_bytes();
   // 8x64 gradient kernels fill the register file and most of LDS (1 workgroup per CU); the narrow
   // networks' kernels fit 2 waves per SIMD, which hides their per-layer latencies
   const bool one_per_cu = grad && P.acc_lds && !(g.WP <= 32 && 2 * (int64_t)lds <= LDS_LIMIT);
@@ -294,18 +366,30 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
     grid = (int)(P.n_tiles < cap ? (P.n_tiles < 1 ? 1 : P.n_tiles) : cap);
   }
 
+  if (batch) {   // one workgroup per CU, one wave per SIMD; slots of T tiles x (L - 1) layers per wave
+    const int T = batch_tiles(g.WP, n.K1);
+    grid = batch_grid(P.n_tiles, T);
+    P.scratch_per_wave = (int64_t)T * (n.L > 1 ? n.L - 1 : 1) * n.K1 * batch_ks(n) * 64;
+  }
+  const int perm = batch ? 1 : 0;   // the batch kernel's k-step-major unit order (fused_batch_kernel.h)
+
   const AdamReq* adam = rq ? rq->adam : nullptr;
   const int packN = g.PW > g.PB ? g.PW : g.PB;
   if (!(adam && adam->packed_valid))
     hipLaunchKernelGGL(k_pack, dim3((packN + 255) / 256), dim3(256), 0, s, n, g.WP, params, (float*)(base + w.wp),
-                       (float*)(base + w.wtp), (float*)(base + w.bp), g.PW, g.PB);
-  if (grad && !P.acc_lds) {   // the workgroups' global gradient copies start from zero
-    if (hipMemsetAsync(P.wg_grads, 0, (size_t)grid * g.PP * 4, s) != hipSuccess) {
+                       (float*)(base + w.wtp), (float*)(base + w.bp), g.PW, g.PB, perm);
+  // gradient copies the reduction reads: one per workgroup, or the batch kernel's shared atomic copies (register-major)
+  const int rmajor = batch && !P.acc_lds ? 1 : 0;
+  const int n_copies = rmajor ? (grid < BATCH_ATOMIC_COPIES ? grid : BATCH_ATOMIC_COPIES) : grid;
+  if (grad && !P.acc_lds) {   // global gradient copies start from zero
+    if (hipMemsetAsync(P.wg_grads, 0, (size_t)n_copies * g.PP * 4, s) != hipSuccess) {
       set_error("hipMemsetAsync failed"); return PINN_ERR_LAUNCH;
     }
   }
   int rc;
-  if (coop) rc = launch_fused_coop(n.K1, grad, P, grid, lds, s);
+  if (batch) rc = g.WP == 16 ? launch_fused_batch<16>(n.W, n.d_in, n.K1, P, grid, lds, s)
+                             : launch_fused_batch<32>(n.W, n.d_in, n.K1, P, grid, lds, s);
+  else if (coop) rc = launch_fused_coop(n.K1, grad, P, grid, lds, s);
   else switch (g.WP) {
     case 16: rc = launch_fused<16>(n.K1, grad, P, grid, lds, s); break;
     case 32: rc = launch_fused<32>(n.K1, grad, P, grid, lds, s); break;
@@ -315,11 +399,11 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
   if (adam) {
     const int64_t np = n.n_params();
     hipLaunchKernelGGL(k_finish_adam, dim3((unsigned)((np + 63) / 64) + 1), dim3(256), 0, s, n, g.WP,
-                       (const float*)P.wg_grads, grid, g.PP, g.PW, (const float*)P.wg_sums, grid,
+                       (const float*)P.wg_grads, n_copies, g.PP, g.PW, (const float*)P.wg_sums, grid,
                        (P.loss_kind & 1) ? rq->n_terms : 0, rq->sums, (P.loss_kind & 2) ? rq->n_cols : 0, rq->mse_sums,
                        rq->grad, adam->params, adam->m, adam->v, (float*)(base + w.wp), (float*)(base + w.wtp),
                        (float*)(base + w.bp), adam->w1, adam->b2, adam->w2, adam->eps, adam->step_size, adam->bc2_sqrt,
-                       adam->n_loss_rows, adam->loss_rows, adam->losses);
+                       adam->n_loss_rows, adam->loss_rows, adam->losses, rq->n_cols, perm | (rmajor << 1));
     return check_launch("fused finish + adam");
   }
   if (rq) {
@@ -330,16 +414,29 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
       hipLaunchKernelGGL(k_reduce_sums, dim3(rq->n_cols), dim3(256), 0, s, (const float*)P.wg_sums, grid, MSE_SUM0,
                          rq->n_cols, rq->mse_sums);
     if (grad) {
-      const int copies = grid;
+      const int copies = n_copies;
       const int64_t np = n.n_params();
       hipLaunchKernelGGL(k_reduce_grads, dim3((unsigned)((np + 63) / 64)), dim3(256), 0, s, n, g.WP,
-                         (const float*)P.wg_grads, copies, g.PP, g.PW, rq->grad);
+                         (const float*)P.wg_grads, copies, g.PP, g.PW, rq->grad, perm | (rmajor << 1));
     }
   }
   return check_launch("fused reductions");
 }
 
 }  // namespace
+
+// batch kernel instances: pinn_fused_batch_w{16,32}_k{3,4}.hip
+template <int WP, int K1>
+int launch_fused_batch_k(int W, int d_in, const FusedParams& P, int grid, size_t lds, hipStream_t s);
+template <int WP>
+int launch_fused_batch(int W, int d_in, int K1, const FusedParams& P, int grid, size_t lds, hipStream_t s) {
+  return K1 == 3 ? launch_fused_batch_k<WP, 3>(W, d_in, P, grid, lds, s) : launch_fused_batch_k<WP, 4>(W, d_in, P, grid, lds, s);
+}
+template int launch_fused_batch<16>(int, int, int, const FusedParams&, int, size_t, hipStream_t);
+template int launch_fused_batch<32>(int, int, int, const FusedParams&, int, size_t, hipStream_t);
+bool fused_batch_has_kernel(int WP, int W, int d_in, int K1, int act) {
+  return (WP == 16 || WP == 32) && W >= 1 && d_in <= 8 && (K1 == 3 || K1 == 4) && act == PINN_ACT_TANH;
+}
 
 bool fused_supports(const Net& n, bool want_grad) {
   if (n.L + 1 > MAX_LOCKS) return false;

@@ -395,7 +395,8 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
 }  // namespace
 
 bool wide_supports(const Net& n) {
-  if (n.prec == PINN_PREC_BF16 && n.L > 49) return false;   // k_chain_fwd keeps every layer's bias in LDS, behind its ring
+  // bf16 mode: k_chain_fwd8 keeps every layer's bias in LDS behind its weight ring; the depth limit is its LDS formula
+  if (n.prec == PINN_PREC_BF16 && chain_fwd8_lds_bytes(n.W <= 128 ? 8 : 16, n.L, true) > CHAIN_LDS_LIMIT) return false;
   return n.act == PINN_ACT_TANH && n.W > 64 && n.W <= 256 && n.d_in <= 16 && n.d_out <= 16 && n.L >= 1 &&
          (n.K1 == 1 || n.K1 == 3 || n.K1 == 4);
 }

@@ -118,6 +118,14 @@ class DNN(nn.Module):
             self._flatten()
         return self._flat
 
+    def write_token(self):
+        """Changes whenever a Parameter of this module (or the flat buffer) is written in place through torch
+        (optimizer.step, load_state_dict, clipping, p.mul_()): the version counters of every alias family of the flat
+        buffer.  `p.data = flat[...]` gives each Parameter a counter of its own, so the flat buffer's alone would miss
+        those writes (Engine.loss_grad_adam_step's packed-weights token)."""
+        flat = self.flat_params()
+        return (id(flat), flat._version) + tuple(p._version for p in self._ordered_params())
+
     def __setstate__(self, state):
         super().__setstate__(state)
         if "layer_sizes" not in self.__dict__:          # a pickle written by the reference's class

@@ -13,7 +13,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import (ACT_LEAKY_RELU, ACT_TANH, ENGINE_AUTO, ENGINE_FUSED, ENGINE_FUSED_COOP, ENGINE_FUSED_TILE, ENGINE_GENERIC,
+from ._lib import (ACT_LEAKY_RELU, ACT_TANH, ENGINE_AUTO, ENGINE_FUSED, ENGINE_FUSED_BATCH, ENGINE_FUSED_COOP, ENGINE_FUSED_TILE, ENGINE_GENERIC,
                    ENGINE_WIDE, RES_CONTINUITY_FTEMP,
                    RES_CONTINUITY_ONLY, RES_NAVIER_STOKES, RES_PHYSICS_EQUATION, RES_TERMS, PinnDesc, PinnError,
                    PinnResidualSpec, check)
@@ -159,7 +159,7 @@ class Engine:
         self._cdesc: Dict[Tuple[int, int], PinnDesc] = {}
         self._ws: Dict[int, torch.Tensor] = {}
         self._ws_need: Dict[Tuple[int, int], int] = {}
-        self._packed_tok = None      # (workspace, params storage, params version) after loss_grad_adam_step
+        self._packed_tok = None      # (workspace, params storage, params version, caller's token) after loss_grad_adam_step
         self.dropout_seed = 0        # training-mode dropout: the caller sets a fresh seed per forward pass; the
                                      # reverse sweep of that pass must run under the same one (include/pinn_hip.h)
         cnt = C.c_int64()
@@ -327,7 +327,8 @@ class Engine:
     def loss_grad_adam_step(self, spec: ResidualSpec, term_scale, params, X, n_res: int, grad, m, v, step: int, lr,
                             T: Optional[torch.Tensor] = None, out_col: Sequence[int] = (), col_scale=None,
                             term_sums=None, col_sums=None, beta1=0.9, beta2=0.999, eps=1e-8,
-                            loss_rows: Optional[torch.Tensor] = None, losses: Optional[torch.Tensor] = None) -> bool:
+                            loss_rows: Optional[torch.Tensor] = None, losses: Optional[torch.Tensor] = None,
+                            params_token=None) -> bool:
         """train.py:189-193 in two launches (pinn_loss_grad_adam_step): loss + gradient at `params`, then ONE kernel
         that finishes sums and gradient, applies Adam to params / m / v and refreshes the packed weights of this N's
         workspace; with `loss_rows` (rows x (len(out_col) + n_terms)) it also writes losses = loss_rows @ [col sums | term sums].
@@ -335,7 +336,11 @@ class Engine:
         (pinn_adam_loop), iteration i writing losses[i].
         Returns False — nothing launched — when the request is not a one-pass request of the fused engine.
         The packing kernel is skipped when the previous call on this engine was this method and `params` has not
-        been written since (same storage, same torch version counter, same workspace)."""
+        been written since: same workspace, same storage, same torch version counter of `params` AND the same
+        `params_token`.  torch's version counter is per alias family: tensors that share `params`' storage through
+        `.data` (dnn.DNN's Linear weights, `p.data = flat[...]`) have counters of their own, so a caller whose buffer
+        is aliased that way passes a token that changes whenever any alias is written (DNN.write_token(): the
+        Parameters' version counters); writes no counter sees (`p.data.mul_()`) need invalidate_packed()."""
         N, nc = X.shape[0], len(out_col)
         lrs = [float(x) for x in lr] if isinstance(lr, (list, tuple)) else None
         self._chk(params, "params", (self.n_params,)); self._chk(X, "X", (N, self.desc.d_in))
@@ -353,7 +358,8 @@ class Engine:
             self._chk(losses, "losses", (n_rows,) if lrs is None else (len(lrs), n_rows))
         ws = self.workspace(N)
         tok = self._packed_tok
-        packed_valid = tok is not None and tok[0] is ws and tok[1] == params.data_ptr() and tok[2] == params._version
+        packed_valid = (tok is not None and tok[0] is ws and tok[1] == params.data_ptr() and tok[2] == params._version
+                        and tok[3] == params_token and tok[4] == N)      # (N picks the kernel, and with it the packed layout)
         self._packed_tok = None
         st = _lib.PinnAdamState(_ptr(m), _ptr(v), int(step), 0.0 if lrs is not None else float(lr), float(beta1), float(beta2),
                                 float(eps), 1 if packed_valid else 0, n_rows, _ptr(loss_rows), _ptr(losses))
@@ -370,8 +376,13 @@ class Engine:
         if rc == _lib.ERR_UNSUPPORTED:
             return False
         check(rc, "pinn_loss_grad_adam_step" if lrs is None else "pinn_adam_loop")
-        self._packed_tok = (ws, params.data_ptr(), params._version)
+        self._packed_tok = (ws, params.data_ptr(), params._version, params_token, N)
         return True
+
+    def invalidate_packed(self):
+        """Forget the packed copy of the parameters left in the workspace by loss_grad_adam_step: the next call re-packs.
+        For writers torch's version counters cannot see (a `.data` view written in place, a raw pointer)."""
+        self._packed_tok = None
 
     def adam_step(self, params, grad, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8):
         for t, nme in ((params, "params"), (grad, "grad"), (m, "exp_avg"), (v, "exp_avg_sq")):

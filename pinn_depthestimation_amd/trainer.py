@@ -99,7 +99,7 @@ class HipEvaluator:
         self.eng.adam_step(theta, grad, m, v, step, lr)
 
     def adam_iteration(self, theta, Xf, Tf, fid_scale, Xr, res_scale, grad, fid_sums, res_sums, m, v, step, lr,
-                       loss_rows=None, losses=None) -> bool:
+                       loss_rows=None, losses=None, params_token=None) -> bool:
         """loss_func + backward + Adam.step (train.py:189-193) in two launches where the engine can
         (Engine.loss_grad_adam_step); False — nothing done — otherwise: the caller then runs __call__ + adam_step."""
         if (self.eng_drop is not None and self.training) or Xr is None or Xr.shape[0] == 0:
@@ -109,17 +109,17 @@ class HipEvaluator:
             if fid_sums.numel():       # (a configuration with fidelity outputs but no fidelity points: classic path)
                 return False
             return self.eng.loss_grad_adam_step(self.spec, res_scale, theta, Xr, Xr.shape[0], grad, m, v, step, lr,
-                                                term_sums=res_sums, loss_rows=loss_rows, losses=losses)
+                                                term_sums=res_sums, loss_rows=loss_rows, losses=losses, params_token=params_token)
         if Xf is Xr:                                       # train_newmethod.py:122-159: one point set for both terms
             return self.eng.loss_grad_adam_step(self.spec, res_scale, theta, Xr, -1, grad, m, v, step, lr, T=Tf,
                                                 out_col=self.fid_cols, col_scale=fid_scale, term_sums=res_sums,
-                                                col_sums=fid_sums, loss_rows=loss_rows, losses=losses)
+                                                col_sums=fid_sums, loss_rows=loss_rows, losses=losses, params_token=params_token)
         if not (self.merge_sets and Xf.shape[0] <= self.MERGE_MAX_FID):
             return False
         cat = self._merged(Xr, Xf)
         return self.eng.loss_grad_adam_step(self.spec, res_scale, theta, cat, Xr.shape[0], grad, m, v, step, lr, T=Tf,
                                             out_col=self.fid_cols, col_scale=fid_scale, term_sums=res_sums,
-                                            col_sums=fid_sums, loss_rows=loss_rows, losses=losses)
+                                            col_sums=fid_sums, loss_rows=loss_rows, losses=losses, params_token=params_token)
 
     def _merged(self, Xr, Xf):
         """[collocation points ; fidelity points] in one matrix, refreshed whenever either source is a different
@@ -154,6 +154,7 @@ class PINN:
         self.config, self.device = cfg, torch.device(device)
         self.reducer = reducer or Reducer()
         self.fold_adam, self._adam_folded, self._folded_iters, self._run_losses = bool(fold_adam), False, 0, None
+        self._fold_refused = None   # key of the (evaluator, point sets) whose folded request the engine has refused
         self.layers = cfg.layers                                           # train.py:52-56
         self.dnn = dnn if dnn is not None else DNN(cfg.layers, cfg.dropout_rate, cfg.init_type)
         self.dnn.to(self.device)
@@ -262,7 +263,7 @@ class PINN:
         vec = self._ring[len(self._ring_iters)] if logged else self._loss_vec
         self._adam_folded = _adam is not None and self.evaluator.adam_iteration(
             self.theta, self.Xf, self.Tf, self._fid_scale, Xr, self._res_scale, self.grad, self._fid_sums, self._res_sums,
-            *_adam, loss_rows=self._loss_mat, losses=vec)
+            *_adam, loss_rows=self._loss_mat, losses=vec, params_token=self.dnn.write_token())
         if not self._adam_folded:
             self.buf.zero_()
             self.evaluator(self.theta, self.Xf, self.Tf, self._fid_scale, Xr, self._res_scale, self.grad,
@@ -362,10 +363,11 @@ class PINN:
         """zero_grad / loss_func / backward / Adam.step / StepLR.step (train.py:189-193)."""
         # One process, no checkpoint inside this iteration (the reference saves the PRE-update weights from inside
         # loss_func, train.py:175-179): the evaluator may fold the update into the pass's last kernel.
-        fold = (self.fold_adam and not self.reducer.active and hasattr(self.evaluator, "adam_iteration")
-                and not self._checkpoint_due(self.iter + 1))
+        fold = (self._may_fold() and not self._checkpoint_due(self.iter + 1))
         loss = self.loss_func((self._adam_m, self._adam_v, self._adam_step + 1, self.current_lr()) if fold else None)
         self._adam_step += 1
+        if fold and not self._adam_folded:
+            self._fold_refused = self._fold_key()      # remembered: no second refused C call per iteration from now on
         if not self._adam_folded:
             self.evaluator.adam_step(self.theta, self.grad, self._adam_m, self._adam_v, self._adam_step,
                                      self.current_lr())
@@ -376,12 +378,21 @@ class PINN:
 
     MAX_RUN = 256      # iterations enqueued by one call (pinn_adam_loop)
 
+    def _fold_key(self):
+        return (id(self.evaluator), id(self.Xr), id(self.Xf), self.residual_batch)
+
+    def _may_fold(self) -> bool:
+        """The folded iteration is worth asking for: switched on, one process, an evaluator that has it, and the engine
+        has not already refused this very request (wide / generic engine, a large split request: the refusal is remembered
+        per evaluator and point sets instead of being re-discovered by two refused C calls every iteration)."""
+        return (self.fold_adam and not self.reducer.active and hasattr(self.evaluator, "adam_iteration")
+                and self._fold_refused != self._fold_key())
+
     def _foldable_run(self, n: int) -> int:
         """How many of the next n Adam iterations can be enqueued by ONE call: full batch, one process, nothing the
         host must do in between (a checkpoint is saved from inside loss_func with pre-update weights, train.py:175-179;
         the prediction dump of train_newmethod.py:141-153 happens at the start of its iteration)."""
-        if not (self.fold_adam and not self.reducer.active and hasattr(self.evaluator, "adam_iteration")
-                and self.residual_batch is None):
+        if not (self._may_fold() and self.residual_batch is None):
             return 0
         k = min(n, self.MAX_RUN)
         for i in range(1, k + 1):
@@ -405,9 +416,11 @@ class PINN:
         call (two launches per iteration, no Python in between); the rest go through adam_step()."""
         while n > 0:
             k = self._foldable_run(n)
-            if k > 1 and self._adam_run(k):
-                n -= k
-                continue
+            if k > 1:
+                if self._adam_run(k):
+                    n -= k
+                    continue
+                self._fold_refused = self._fold_key()
             self.adam_step()
             n -= 1
 
@@ -423,7 +436,7 @@ class PINN:
         out = self._run_losses[:k]
         if not self.evaluator.adam_iteration(self.theta, self.Xf, self.Tf, self._fid_scale, self.Xr, self._res_scale, self.grad,
                                              self._fid_sums, self._res_sums, self._adam_m, self._adam_v, self._adam_step + 1,
-                                             lrs, loss_rows=self._loss_mat, losses=out):
+                                             lrs, loss_rows=self._loss_mat, losses=out, params_token=self.dnn.write_token()):
             return False
         if self.log_every == 1:                      # every iteration logged: one copy into the ring
             r0 = len(self._ring_iters)

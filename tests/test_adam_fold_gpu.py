@@ -220,3 +220,46 @@ def test_runs_of_iterations_log_the_same_iterations_as_the_per_iteration_loop(tm
     assert torch.equal(res[False][0], res[True][0])
     assert [r[0] for r in res[True][1]] == [r[0] for r in res[False][1]] == [i for i in range(1, 121) if i % 7 == 0]
     assert np.allclose(np.array(res[True][1])[:, 1:], np.array(res[False][1])[:, 1:], rtol=2e-6, atol=0.0)
+
+
+def test_writes_through_the_modules_parameters_invalidate_the_packed_weights():
+    """ADVICE r2 (engine.py packed-weights token): DNN's Parameters alias the flat buffer through `.data`, so torch bumps
+    THEIR version counters, not the flat tensor's.  A write through a Parameter (load_state_dict, p.mul_()) between two
+    folded iterations must make the next pass re-pack; the token now carries DNN.write_token()."""
+    from pinn_depthestimation_amd.dnn import DNN
+    desc, spec, flat0, X, T, scale, cscale, fid, n_res = _setup("ns8x64_res_only")
+    P = flat0.numel()
+    g = torch.Generator().manual_seed(5)
+    other = O.flatten(O.init_params(O.layer_sizes(3, 8, 64, 4), "xavier", g))
+    out = {}
+    for mode in ("classic", "folded"):
+        torch.manual_seed(0)
+        dnn = DNN([3] + [64] * 8 + [4], 0.0, "xavier").cuda()
+        th = dnn.flat_params()
+        th.copy_(flat0)
+        donor = DNN([3] + [64] * 8 + [4], 0.0, "xavier")
+        donor.flat_params().copy_(other)
+        eng = Engine(desc)
+        m, v, grad = torch.zeros(P, device="cuda"), torch.zeros(P, device="cuda"), torch.zeros(P, device="cuda")
+        ts = torch.zeros(spec.n_terms, device="cuda")
+        sums = []
+        for step in range(1, 6):
+            if step == 3:
+                v_flat = th._version
+                dnn.load_state_dict(donor.state_dict())          # param.copy_(): bumps the Parameters' counters only
+                assert th._version == v_flat, "the premise of this test: the flat buffer's counter does not see it"
+                assert torch.equal(dnn.flat_params().cpu(), other)
+            if step == 5:
+                with torch.no_grad():
+                    next(dnn.parameters()).mul_(1.5)             # an in-place write through one Parameter
+            if mode == "folded":
+                assert eng.loss_grad_adam_step(spec, scale, th, X, X.shape[0], grad, m, v, step, 1e-3, term_sums=ts,
+                                               params_token=dnn.write_token())
+            else:
+                grad.zero_(); eng.residual_loss_grad(spec, scale, th, X, grad, sums=ts); eng.adam_step(th, grad, m, v, step, 1e-3)
+            sums.append(ts.clone())
+        torch.cuda.synchronize()
+        out[mode] = (th.clone(), sums)
+    for k, (a, b) in enumerate(zip(out["classic"][1], out["folded"][1])):
+        assert torch.equal(a, b), f"loss sums differ at iteration {k + 1}: the pass ran on stale packed weights"
+    assert torch.equal(out["classic"][0], out["folded"][0])

@@ -9,8 +9,8 @@ import torch
 
 from oracle import pinn_oracle as O
 from pinn_depthestimation_amd import Engine, NetDesc, ResidualSpec
-from pinn_depthestimation_amd._lib import (ACT_LEAKY_RELU, ACT_TANH, ENGINE_FUSED, ENGINE_FUSED_COOP, ENGINE_FUSED_TILE,
-                                           ENGINE_GENERIC)
+from pinn_depthestimation_amd._lib import (ACT_LEAKY_RELU, ACT_TANH, ENGINE_FUSED, ENGINE_FUSED_BATCH, ENGINE_FUSED_COOP,
+                                           ENGINE_FUSED_TILE, ENGINE_GENERIC)
 
 pytestmark = pytest.mark.gpu
 
@@ -60,19 +60,22 @@ def rel_l2(a, b):
 ENGINES = [ENGINE_GENERIC, ENGINE_FUSED]
 
 
-@pytest.fixture(autouse=True, params=["tile", "coop"])
+@pytest.fixture(autouse=True, params=["tile", "coop", "batch"])
 def fused_kernel_choice(request, monkeypatch):
     """The fused engine has two kernels at padded width 64: one wave per 16-point tile (k_fused) and four
-    waves per tile (k_fused_coop, picked automatically for small N).  Every test in this module runs with
-    each forced in turn through the descriptor (pinn_desc.engine = PINN_ENGINE_FUSED_TILE / _COOP — the
-    library reads no environment variables); narrower networks have the tile kernel only."""
+    waves per tile (k_fused_coop, picked automatically for small N); networks of width <= 32 have the tile kernel
+    and the batch kernel (k_fused_batch: layer-major batches of 8 tiles per wave, picked automatically for large
+    N; gradient passes only — its forward-only requests run on the tile kernel).  Every test in this module runs
+    with each forced in turn through the descriptor (pinn_desc.engine = PINN_ENGINE_FUSED_TILE / _COOP / _BATCH —
+    the library reads no environment variables)."""
     orig = NetDesc.c_struct
 
     def c_struct(self):
         d = orig(self)
         if d.engine == ENGINE_FUSED:
             coop = request.param == "coop" and 32 < self.width <= 64
-            d.engine = ENGINE_FUSED_COOP if coop else ENGINE_FUSED_TILE
+            batch = request.param == "batch" and self.width <= 32
+            d.engine = ENGINE_FUSED_COOP if coop else (ENGINE_FUSED_BATCH if batch else ENGINE_FUSED_TILE)
         return d
     monkeypatch.setattr(NetDesc, "c_struct", c_struct)
     return request.param
