@@ -49,7 +49,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define PINN_BATCH_T 0     // 0: batch_tiles(); > 0 forces a value (experiments)
 #endif
 #ifndef PINN_BATCH_OCC
-#define PINN_BATCH_OCC 1
+#define PINN_BATCH_OCC 0     // 0: batch_occ(); > 0 forces a value (experiments)
+#endif
+#ifndef PINN_BATCH_OCC16
+#define PINN_BATCH_OCC16 2   // width <= 16: two waves per SIMD (256 registers each) with half the tiles per batch
 #endif
 #ifndef PINN_BATCH_PF
 #define PINN_BATCH_PF 4       // tiles of spilled activations in flight ahead of the reverse sweep
@@ -58,9 +61,19 @@ constexpr int BATCH_PF = PINN_BATCH_PF;
 #ifndef PINN_BATCH_SKIP
 #define PINN_BATCH_SKIP 0     // diagnostic builds only (wrong results): 1 no spill stores, 2 no spill loads, 4 no LDS transposes,
 #endif                        // 8 no weight-gradient MFMAs, 16 no tanh, 32 no gradient flush
+// Tiles per wave and batch: as many as the 512-register file takes WITHOUT a spill (a scratch reload shares the
+// vector-memory counter with the activation prefetch and drains it: bwg_* comment).  hipcc's resource report per
+// instance: width <= 16: 8 tiles at K1 = 3, 4 at K1 = 4; width <= 32: 4 at K1 = 3, 2 at K1 = 4.
+__host__ __device__ constexpr int batch_occ(int WP, int K1) {     // waves per SIMD (= workgroups per CU)
+  return PINN_BATCH_OCC > 0 ? PINN_BATCH_OCC : (WP == 16 ? PINN_BATCH_OCC16 : 1);
+}
+__host__ __device__ constexpr int batch_tiles(int WP, int K1) {
+  return PINN_BATCH_T > 0 ? PINN_BATCH_T
+       : WP == 16 ? (batch_occ(WP, K1) == 2 ? (K1 <= 3 ? 4 : 2) : (K1 <= 3 ? 8 : 4)) : (K1 <= 3 ? 4 : 2);
+}
 constexpr int BATCH_WAVES = 4;
 constexpr int BATCH_THREADS = BATCH_WAVES * 64;
-__host__ __device__ constexpr int batch_pads(int WP, int K1) { return K1 * 2 * (WP / 16) > 8 ? K1 * 2 * (WP / 16) : 8; }   // 1 KB pads per wave
+__host__ __device__ constexpr int batch_pads(int WP, int K1) { return K1 * 2 * (WP / 16) > 4 ? K1 * 2 * (WP / 16) : 4; }   // 1 KB pads per wave
 
 // A-operand fragments of one layer, all output tiles: w[MT][kt] = Wl[16MT + m][16kt + 4kq .. +3]  (row stride LDW)
 template <int NKT, int NT_OUT>
@@ -301,7 +314,7 @@ __device__ __forceinline__ void bwgrad_flush(float* __restrict__ acc, int woff, 
 // WP: padded hidden width (16 / 32); KS = ceil(W / 4): k-steps of a hidden contraction; KS0 = ceil(d_in / 4);
 // T: tiles per wave and batch.  Gradient passes only (the forward-only calls stay on k_fused).
 template <int WP, int KS, int KS0, int K1, int T, int SINK, int ACT, int EPI = EPI_GENERIC>
-__global__ __launch_bounds__(BATCH_THREADS, PINN_BATCH_OCC) void k_fused_batch(const FusedParams P) {
+__global__ __launch_bounds__(BATCH_THREADS, batch_occ(WP, K1)) void k_fused_batch(const FusedParams P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NTH = WP / 16;
   static_assert(KS <= 4 * NTH && KS > 4 * (NTH - 1), "KS must land in the last 16-feature tile of WP");
@@ -572,12 +585,5 @@ __global__ __launch_bounds__(BATCH_THREADS, PINN_BATCH_OCC) void k_fused_batch(c
 template <int WP>
 int launch_fused_batch(int W, int d_in, int K1, const FusedParams& P, int grid, size_t lds_bytes, hipStream_t s);
 bool fused_batch_has_kernel(int WP, int W, int d_in, int K1, int act);
-// Tiles per wave and batch: as many as the 512-register file takes WITHOUT a spill (a scratch reload shares the
-// vector-memory counter with the activation prefetch and drains it: bwg_* comment).  hipcc's resource report per
-// instance: width <= 16: 8 tiles at K1 = 3, 4 at K1 = 4; width <= 32: 4 at K1 = 3, 2 at K1 = 4.
-__host__ __device__ constexpr int batch_tiles(int WP, int K1) {
-  return PINN_BATCH_T > 0 ? PINN_BATCH_T : (WP == 16 ? (K1 <= 3 ? 8 : 4) : (K1 <= 3 ? 4 : 2));
-}
-constexpr int FUSED_BATCH_OCC = PINN_BATCH_OCC;  // waves per SIMD the kernels are compiled for (= workgroups per CU)
 
 }  // namespace pinn

@@ -87,6 +87,7 @@ struct FusedParams {
   int acc_lds;               // 1: the workgroup's gradient copy lives in LDS
   int PW, PB;                // padded weight / bias float counts
   int lds_acc_floats;        // floats reserved for the LDS gradient copy (0 if unused)
+  int batch_T;               // k_fused_batch: tiles per wave and batch of the instance to launch
 };
 
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {

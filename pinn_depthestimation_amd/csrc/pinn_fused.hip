@@ -52,18 +52,25 @@ bool use_coop(const Net& n, const Geo& g, bool grad, int64_t N) {
 bool batch_supported(const Net& n, const Geo& g) {
   return g.WP <= 32 && n.L >= 1 && n.L + 1 <= MAX_LOCKS && fused_batch_has_kernel(g.WP, n.W, n.d_in, n.K1, n.act);
 }
+constexpr int64_t BATCH_MIN_TILES = 256;   // AUTO: below this many tiles (4096 points) the tile kernel keeps the request
 bool use_batch(const Net& n, const Geo& g, bool grad, int64_t N) {
   if (!grad || !batch_supported(n, g)) return false;
   if (n.fused_kernel == FUSED_KERNEL_BATCH) return true;
   if (n.fused_kernel != FUSED_KERNEL_AUTO) return false;
-  return (N + 15) / 16 >= (int64_t)cu_count() * BATCH_WAVES * batch_tiles(g.WP, n.K1) * FUSED_BATCH_OCC;
+  return (N + 15) / 16 >= BATCH_MIN_TILES;
+}
+// tiles per wave and batch: the full batch once every wave of the chip gets one, else ONE tile per wave (the latency of
+// a layer step scales with the batch, and a small point set wants its tiles spread over as many waves as there are)
+int batch_T_for(const Geo& g, int K1, int64_t n_tiles) {
+  const int T = batch_tiles(g.WP, K1);
+  return n_tiles >= (int64_t)cu_count() * BATCH_WAVES * batch_occ(g.WP, K1) * T ? T : 1;
 }
 int64_t batch_lds_fixed_bytes(int WP, int K1) { return (int64_t)(BATCH_WAVES * batch_pads(WP, K1) * TB_FLOATS + BATCH_WAVES * MAX_SUMS) * 4; }
 int batch_ks(const Net& n) { return n.W <= 12 ? 3 : (n.W <= 16 ? 4 : (n.W <= 20 ? 5 : 8)); }   // k-steps of the kernel instance
-int batch_grid(int64_t n_tiles, int T) {
+int batch_grid(int64_t n_tiles, int T, int occ) {
   const int64_t nb = (n_tiles + T - 1) / T;
   const int64_t want = (nb + BATCH_WAVES - 1) / BATCH_WAVES;
-  const int64_t cap = (int64_t)cu_count() * FUSED_BATCH_OCC;
+  const int64_t cap = (int64_t)cu_count() * occ;
   return (int)(want < 1 ? 1 : (want < cap ? want : cap));
 }
 
@@ -97,8 +104,8 @@ WsLayout ws_layout(const Net& n, const Geo& g, int64_t N) {
   if (batch_supported(n, g)) {   // the batch kernel's slots: T tiles x (L - 1) layers x K1 <= 4 x KS x 64 floats per wave
     int64_t b = 0;      // (one workspace serves the K1 = 3 and K1 = 4 instances: the larger of the two)
     for (int k1 = 3; k1 <= 4; ++k1) {
-      const int T = batch_tiles(g.WP, k1);
-      const int64_t bk = (int64_t)batch_grid(n_tiles, T) * BATCH_WAVES * T * (n.L > 1 ? n.L - 1 : 1) * k1 * batch_ks(n) * 64 * 4;
+      const int T = batch_T_for(g, k1, n_tiles);
+      const int64_t bk = (int64_t)batch_grid(n_tiles, T, batch_occ(g.WP, k1)) * BATCH_WAVES * T * (n.L > 1 ? n.L - 1 : 1) * k1 * batch_ks(n) * 64 * 4;
       if (bk > b) b = bk;
     }
     if (b > scratch_bytes) scratch_bytes = b;
@@ -352,7 +359,7 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
   }
   if (batch) {   // the batch kernel carves its own pads (batch_pads per wave); the gradient copy stays in LDS if it still fits
     // a gradient copy per wave in LDS if four of them fit, else atomics into BATCH_ATOMIC_COPIES shared copies (bwgrad_flush)
-    P.acc_lds = ((int64_t)BATCH_WAVES * g.PP * 4 + batch_lds_fixed_bytes(g.WP, n.K1)) * FUSED_BATCH_OCC <= LDS_LIMIT ? 1 : 0;
+    P.acc_lds = ((int64_t)BATCH_WAVES * g.PP * 4 + batch_lds_fixed_bytes(g.WP, n.K1)) * batch_occ(g.WP, n.K1) <= LDS_LIMIT ? 1 : 0;
     P.lds_acc_floats = P.acc_lds ? BATCH_WAVES * g.PP : 0;
   }
   const size_t lds = batch ? (size_t)P.lds_acc_floats * 4 + (size_t)batch_lds_fixed_bytes(g.WP, n.K1)
@@ -367,8 +374,9 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
   }
 
   if (batch) {   // one workgroup per CU, one wave per SIMD; slots of T tiles x (L - 1) layers per wave
-    const int T = batch_tiles(g.WP, n.K1);
-    grid = batch_grid(P.n_tiles, T);
+    const int T = batch_T_for(g, n.K1, P.n_tiles);
+    P.batch_T = T;
+    grid = batch_grid(P.n_tiles, T, batch_occ(g.WP, n.K1));
     P.scratch_per_wave = (int64_t)T * (n.L > 1 ? n.L - 1 : 1) * n.K1 * batch_ks(n) * 64;
   }
   const int perm = batch ? 1 : 0;   // the batch kernel's k-step-major unit order (fused_batch_kernel.h)

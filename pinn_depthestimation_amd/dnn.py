@@ -85,10 +85,14 @@ class DNN(nn.Module):
         return [m for m in self.layers if isinstance(m, nn.Linear)]
 
     def _ordered_params(self):
-        out = []
-        for lin in self._linears():
-            out += [lin.weight, lin.bias]
-        return out
+        # cached: the trainer asks for this list (write_token, flat_params) on every iteration of a host-bound loop
+        ps = self.__dict__.get("_plist")
+        if ps is None:
+            ps = []
+            for lin in self._linears():
+                ps += [lin.weight, lin.bias]
+            self.__dict__["_plist"] = ps
+        return ps
 
     def _flatten(self):
         ps = self._ordered_params()
@@ -118,16 +122,19 @@ class DNN(nn.Module):
             self._flatten()
         return self._flat
 
-    def write_token(self):
+    def write_token(self, flat=None):
         """Changes whenever a Parameter of this module (or the flat buffer) is written in place through torch
         (optimizer.step, load_state_dict, clipping, p.mul_()): the version counters of every alias family of the flat
         buffer.  `p.data = flat[...]` gives each Parameter a counter of its own, so the flat buffer's alone would miss
         those writes (Engine.loss_grad_adam_step's packed-weights token)."""
-        flat = self.flat_params()
-        return (id(flat), flat._version) + tuple(p._version for p in self._ordered_params())
+        flat = self._flat if flat is None else flat     # (the caller's flat_params() result: already validated)
+        if flat is None:
+            flat = self.flat_params()
+        return (id(flat), flat._version) + tuple([p._version for p in self._ordered_params()])
 
     def __setstate__(self, state):
         super().__setstate__(state)
+        self.__dict__.pop("_plist", None)
         if "layer_sizes" not in self.__dict__:          # a pickle written by the reference's class
             lins = self._linears()
             self.layer_sizes = [lins[0].in_features] + [l.out_features for l in lins]

@@ -263,7 +263,7 @@ class PINN:
         vec = self._ring[len(self._ring_iters)] if logged else self._loss_vec
         self._adam_folded = _adam is not None and self.evaluator.adam_iteration(
             self.theta, self.Xf, self.Tf, self._fid_scale, Xr, self._res_scale, self.grad, self._fid_sums, self._res_sums,
-            *_adam, loss_rows=self._loss_mat, losses=vec, params_token=self.dnn.write_token())
+            *_adam, loss_rows=self._loss_mat, losses=vec, params_token=self.dnn.write_token(self.theta))
         if not self._adam_folded:
             self.buf.zero_()
             self.evaluator(self.theta, self.Xf, self.Tf, self._fid_scale, Xr, self._res_scale, self.grad,
@@ -436,7 +436,7 @@ class PINN:
         out = self._run_losses[:k]
         if not self.evaluator.adam_iteration(self.theta, self.Xf, self.Tf, self._fid_scale, self.Xr, self._res_scale, self.grad,
                                              self._fid_sums, self._res_sums, self._adam_m, self._adam_v, self._adam_step + 1,
-                                             lrs, loss_rows=self._loss_mat, losses=out, params_token=self.dnn.write_token()):
+                                             lrs, loss_rows=self._loss_mat, losses=out, params_token=self.dnn.write_token(self.theta)):
             return False
         if self.log_every == 1:                      # every iteration logged: one copy into the ring
             r0 = len(self._ring_iters)

@@ -22,6 +22,10 @@ CASES = {
     "ns8x64_split": (3, 4, 8, 64, (0, 1, 2), "Navier_Stokes", ("t", "x", "y"), ("h", "z", "u", "v"), (2, 3), 243, 12),
     "pe10x10_split": (2, 6, 10, 10, (0, 1), "physics_equation", ("x", "y"), ("h", "U", "V", "eta_mean", "Hrms", "k"), (0, 1, 2, 3, 4, 5), 243, 12),
     "co100x20_newmethod": (2, 3, 100, 20, (0, 1), "continuity_only", ("x", "y"), ("U", "V", "h"), (0, 1), 1251, None),
+    # enough points for AUTO to pick the batch kernel (k_fused_batch: k-step-major packing, its own gradient sinks):
+    # the folded finish kernel must un-permute / re-pack in that layout too
+    "pe10x10_split_batch": (2, 6, 10, 10, (0, 1), "physics_equation", ("x", "y"), ("h", "U", "V", "eta_mean", "Hrms", "k"), (0, 1, 2, 3, 4, 5), 6000, 12),
+    "co40x20_newmethod_batch": (2, 3, 40, 20, (0, 1), "continuity_only", ("x", "y"), ("U", "V", "h"), (0, 1), 5000, None),
 }
 
 
