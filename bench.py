@@ -126,13 +126,35 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
+def visible_gpu_count() -> int:
+    """GPUs this process could open, counted WITHOUT loading HIP (no torch.cuda, no libamdhip64): the launcher must
+    stay a process that never touched the GPU.  An explicit *_VISIBLE_DEVICES list wins; otherwise the KFD topology
+    nodes that have SIMDs (CPUs are nodes too) capped by the DRM render nodes this container may actually open."""
+    import glob
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    kfd = 0
+    for props in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(props):
+                k, _, val = line.partition(" ")
+                if k == "simd_count" and int(val) > 0:
+                    kfd += 1
+        except (OSError, ValueError):
+            pass
+    render = [d for d in glob.glob("/dev/dri/renderD*") if os.access(d, os.R_OK | os.W_OK)]
+    return min(kfd, len(render)) if render else 0
+
+
 def launch_ranks(args, argv) -> int:
-    """Start args.gpus ranks of this script as child processes and wait for them.  This process makes NO GPU
-    call (torch.cuda.device_count() does not initialise the GPU on this image; the children do)."""
+    """Start args.gpus ranks of this script as child processes and wait for them.  This process makes NO GPU call and
+    loads no GPU runtime: the device count comes from sysfs (visible_gpu_count); every child checks again for itself
+    with the real runtime and refuses to share a card."""
     n = args.gpus
     if not args.test_evaluator:
-        import torch
-        have = torch.cuda.device_count()
+        have = visible_gpu_count()
         if have < n:
             print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible; refusing to run a smaller job under "
                   f"that name", file=sys.stderr, flush=True)

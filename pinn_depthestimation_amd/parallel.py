@@ -27,8 +27,10 @@ def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
 class Reducer:
     """Sum-all-reduce over the data-parallel group; a no-op for a single process."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, force: bool = False):
+        """force = True runs every collective even in a world of one (rehearsal of the RCCL path on a single GPU)."""
         self.group = group
+        self.force = bool(force)
         self.dist = None
         self.world, self.rank = 1, 0
         try:
@@ -42,7 +44,7 @@ class Reducer:
 
     @property
     def active(self) -> bool:
-        return self.world > 1
+        return self.world > 1 or (self.force and self.dist is not None)
 
     def allreduce_sum_(self, buf: torch.Tensor) -> torch.Tensor:
         if self.active:
