@@ -60,19 +60,22 @@ extern "C" {
 #define PINN_ENGINE_AUTO 0
 #define PINN_ENGINE_GENERIC 1  /* layer-by-layer VALU kernels, any shape */
 #define PINN_ENGINE_FUSED 2    /* MFMA chain kernel, one persistent launch, hidden width <= 64 */
-#define PINN_ENGINE_WIDE 3     /* MFMA chain, one launch per layer, 64 < hidden width <= 256 */
+#define PINN_ENGINE_WIDE 3     /* 64 < hidden width <= 256.  PINN_PREC_F32: one launch per layer, jets in HBM (wide_kernel.h);
+                                * PINN_PREC_BF16: the chain engine, three kernels for all hidden matrices (chain_kernel.h) */
 /* sub-values of PINN_ENGINE_FUSED: which of its kernels runs (AUTO / FUSED choose by point count).
  * They are part of the descriptor, not of the process environment: the library reads no
  * environment variables and keeps no mutable state that changes results. */
 #define PINN_ENGINE_FUSED_TILE 4  /* one wave per 16-point tile (the large-N kernel) */
 #define PINN_ENGINE_FUSED_COOP 5  /* four waves per tile (small point sets; padded hidden width 64 only) */
-#define PINN_ENGINE_FUSED_BATCH 6 /* layer-major batches of 8 tiles per wave (narrow nets, hidden width <= 32, gradient
-                                   * passes; AUTO picks it from ~1.3e5 points; other requests fall back to _TILE) */
+#define PINN_ENGINE_FUSED_BATCH 6 /* layer-major batches of tiles per wave (narrow nets: hidden width <= 32, tanh, gradient
+                                   * passes; AUTO picks it from 4096 points; other requests fall back to _TILE) */
 
 /* GEMM operand precision.  Everything outside the MFMAs (tanh, residual, adjoints, gradient
  * accumulation, Adam) is fp32 in both modes. */
 #define PINN_PREC_F32 0   /* v_mfma_f32_16x16x4_f32: exact fp32 (the reference's precision) */
-#define PINN_PREC_BF16 1  /* v_mfma_f32_16x16x16_bf16: bf16 operands, fp32 accumulate (BASELINE configs[3]); wide engine only */
+#define PINN_PREC_BF16 1  /* v_mfma_f32_16x16x32_bf16: bf16 operands (weights split hi + lo, jets rounded to bf16), fp32 accumulate
+                           * (BASELINE configs[3]); wide engine only.  A tolerance mode, not fp32 parity: loss / gradient within
+                           * 5e-3 of the reference at 12 x 256 (measured 2.8e-3 / 3.3e-3, tests/test_config3_gpu.py) */
 
 /* error codes */
 #define PINN_OK 0

@@ -88,6 +88,7 @@ struct FusedParams {
   int PW, PB;                // padded weight / bias float counts
   int lds_acc_floats;        // floats reserved for the LDS gradient copy (0 if unused)
   int batch_T;               // k_fused_batch: tiles per wave and batch of the instance to launch
+  int io1;                   // k_fused<..., IO1 = true>: inputs / outputs in k-step-major order (see k_fused)
 };
 
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
@@ -110,8 +111,8 @@ __device__ __forceinline__ void load_w(const float* __restrict__ Wl, f4 (&w)[NT_
       w[MT][kt] = *reinterpret_cast<const f4*>(Wl + (16 * MT + m) * LDW + 16 * kt + 4 * kq);
 }
 
-// acc[c][MT] += sum_k W[16MT + m][k] * bin[c][k]
-template <int NT_IN, int NT_OUT, int K1>
+// acc[c][MT] += sum_k W[16MT + m][k] * bin[c][k]      (KR < 4: only the first KR k-steps of every k-tile carry data)
+template <int NT_IN, int NT_OUT, int K1, int KR = 4>
 __device__ __forceinline__ void gemm_chain(const f4 (&w)[NT_OUT][NT_IN], const f4 (&bin)[K1][NT_IN],
                                            f4 (&acc)[K1][NT_OUT]) {
 #pragma unroll
@@ -119,7 +120,7 @@ __device__ __forceinline__ void gemm_chain(const f4 (&w)[NT_OUT][NT_IN], const f
 #pragma unroll
     for (int kt = 0; kt < NT_IN; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < KR; ++r)
 #pragma unroll
         for (int c = 0; c < K1; ++c) acc[c][MT] = mfma4(w[MT][kt][r], bin[c][kt][r], acc[c][MT]);
 }
@@ -686,8 +687,17 @@ __device__ __forceinline__ void loss_epilogue(const FusedParams& P, const f4 (&o
 #define PINN_STAMP(i) do { } while (0)
 #endif
 
-template <int WP, int K1, bool GRAD, bool LDSACC, int ACT, int EPI = EPI_GENERIC>
+// KRO > 0 (the specialised-epilogue kernels of width 64): network inputs and outputs sit in K-STEP-MAJOR order — input
+// column f at padded index perm16(f) = 4 (f & 3) + (f >> 2), i.e. lane group f, register 0 for d_in <= 4, and output o at
+// padded row perm16(o) — so the first layer's forward GEMM is ONE k-step instead of four and the output layer's reverse
+// GEMM KRO = ceil(d_out / 4) k-steps (Navier-Stokes 3 -> 8x64 -> 4: 96 of the tile's 5696 MFMAs gone).  The packing
+// kernels place the weights accordingly (pinn_fused.hip, PACK_IN / PACK_OUT) and the host hands the epilogue PADDED row
+// indices in out_col / dir_col, so the epilogue code is the same.
+template <int WP, int K1, bool GRAD, bool LDSACC, int ACT, int EPI = EPI_GENERIC, int KRO = 0>
 __global__ __launch_bounds__(FUSED_THREADS, WP == 16 ? PINN_FUSED_W16_WAVES : FUSED_WAVES / 4) void k_fused(const FusedParams P) {
+  constexpr bool IO1 = KRO > 0;
+  constexpr int KRI = IO1 ? 1 : 4;          // k-steps of the first layer's contraction (d_in <= 4 when IO1)
+  constexpr int KRL = IO1 ? KRO : 4;        // k-steps of the output layer's reverse contraction
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NTH = WP / 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -732,7 +742,7 @@ __global__ __launch_bounds__(FUSED_THREADS, WP == 16 ? PINN_FUSED_W16_WAVES : FU
     pc = pc < P.N ? pc : P.N - 1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int f = 4 * q + r;
+      const int f = IO1 ? (r == 0 ? q : 16) : 4 * q + r;      // (IO1: column q in register 0, nothing else)
       x[r] = (f < P.d_in) ? P.X[pc * P.d_in + f] : 0.f;
     }
   };
@@ -752,11 +762,12 @@ __global__ __launch_bounds__(FUSED_THREADS, WP == 16 ? PINN_FUSED_W16_WAVES : FU
     auto input_jet = [&](f4 (&b)[K1][1]) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int f = 4 * q + r;
+        const int f = 4 * q + r;                 // PADDED input index (dir_col holds padded indices when IO1)
 #if PINN_FUSED_XPREF
         b[0][0][r] = xcur[r];
 #else
-        b[0][0][r] = (f < P.d_in) ? P.X[ptc * P.d_in + f] : 0.f;
+        const int fr = IO1 ? (r == 0 ? q : 16) : f;
+        b[0][0][r] = (fr < P.d_in) ? P.X[ptc * P.d_in + fr] : 0.f;
 #endif
 #pragma unroll
         for (int c = 1; c < K1; ++c) b[c][0][r] = (f == P.dir_col[c - 1]) ? 1.f : 0.f;
@@ -776,7 +787,7 @@ __global__ __launch_bounds__(FUSED_THREADS, WP == 16 ? PINN_FUSED_W16_WAVES : FU
       load_bias<NTH>(Bp_ + b_off_p<WP>(0), bias, q);
       f4 acc0[K1][NTH];
       zero_tiles<NTH, K1>(acc0);
-      gemm_chain<1, NTH, K1>(w0, b0, acc0);
+      gemm_chain<1, NTH, K1, KRI>(w0, b0, acc0);
       PINN_STAMP(0);
       activate_to<ACT, NTH, K1>(acc0, bias, a);
     }
@@ -839,7 +850,7 @@ __global__ __launch_bounds__(FUSED_THREADS, WP == 16 ? PINN_FUSED_W16_WAVES : FU
       {
         f4 g[K1][NTH];
         zero_tiles<NTH, K1>(g);
-        gemm_chain<1, NTH, K1>(wtl, G, g);
+        gemm_chain<1, NTH, K1, KRL>(wtl, G, g);
         activate_adjoint_to<ACT, NTH, K1>(g, a, z);
       }
       for (int l = L - 1; l >= 1; --l) {

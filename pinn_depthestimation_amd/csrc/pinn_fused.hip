@@ -122,10 +122,16 @@ WsLayout ws_layout(const Net& n, const Geo& g, int64_t N) {
 // units and network inputs in k-step-major order, j <-> 16*(j/16) + perm16(j%16) (an involution, so the same formula
 // maps a real unit to its padded index); network outputs always stay in natural order.
 __host__ __device__ inline int unit_at(int j, bool permuted) { return permuted ? (j & ~15) + perm16(j & 15) : j; }
+// packing flags: PACK_PERM = the batch kernel's order (hidden units and inputs permuted, outputs natural); PACK_RMAJOR =
+// register-major gradient blocks (reduction kernels only); PACK_IN / PACK_OUT = ONLY the network inputs / outputs
+// permuted (k_fused<..., KRO > 0>: one k-step for the first layer, ceil(d_out / 4) for the output layer's reverse GEMM)
+constexpr int PACK_PERM = 1, PACK_RMAJOR = 2, PACK_IN = 4, PACK_OUT = 8;
+__host__ __device__ inline bool row_permuted(int flags, int l, int L) { return l < L ? (flags & PACK_PERM) != 0 : (flags & PACK_OUT) != 0; }
+__host__ __device__ inline bool col_permuted(int flags, int l) { return (flags & PACK_PERM) != 0 || (l == 0 && (flags & PACK_IN) != 0); }
 
 // flat torch-layout parameters -> padded row-major W, padded transposed W, padded bias
 __global__ void k_pack(Net n, int WP, const float* __restrict__ params, float* __restrict__ Wp,
-                       float* __restrict__ WTp, float* __restrict__ Bp, int PW, int PB, int perm) {
+                       float* __restrict__ WTp, float* __restrict__ Bp, int PW, int PB, int flags) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < PW) {
     // which layer block does padded index i fall in?
@@ -140,18 +146,18 @@ __global__ void k_pack(Net n, int WP, const float* __restrict__ params, float* _
     const int in_d = n.in_dim(l), out_d = n.out_dim(l);
     const int base = i - rem;
     {  // row-major [out][in]
-      const int o = unit_at(rem / inP, perm && l < n.L), c = unit_at(rem % inP, perm);
+      const int o = unit_at(rem / inP, row_permuted(flags, l, n.L)), c = unit_at(rem % inP, col_permuted(flags, l));
       Wp[i] = (o < out_d && c < in_d) ? params[n.w_off(l) + (int64_t)o * in_d + c] : 0.f;
     }
     {  // transposed [in][out]
-      const int c = unit_at(rem / outP, perm), o = unit_at(rem % outP, perm && l < n.L);
+      const int c = unit_at(rem / outP, col_permuted(flags, l)), o = unit_at(rem % outP, row_permuted(flags, l, n.L));
       WTp[base + rem] = (o < out_d && c < in_d) ? params[n.w_off(l) + (int64_t)o * in_d + c] : 0.f;
     }
   }
   if (i < PB) {
     int l = i / WP, o = i % WP;
     if (l >= n.L) { l = n.L; o = i - n.L * WP; }
-    o = unit_at(o, perm && l < n.L);
+    o = unit_at(o, row_permuted(flags, l, n.L));
     Bp[i] = (o < n.out_dim(l)) ? params[n.b_off(l) + o] : 0.f;
   }
 }
@@ -192,7 +198,7 @@ __device__ __forceinline__ float sum_copies(const float* __restrict__ wg, int64_
 
 __global__ void k_reduce_grads(Net n, int WP, const float* __restrict__ wg, int copies, int PP, int PW,
                                float* __restrict__ grad, int flags) {
-  const int perm = flags & 1, rmajor = flags >> 1;   // rmajor: [r][lane] inside a 16x16 block (bwgrad_flush, BSINK_ATOMIC)
+  const int rmajor = (flags & PACK_RMAJOR) != 0;   // [r][lane] inside a 16x16 block (bwgrad_flush, BSINK_ATOMIC)
   __shared__ float part[4][64];
   const int lane_p = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + lane_p;
@@ -206,10 +212,10 @@ __global__ void k_reduce_grads(Net n, int WP, const float* __restrict__ wg, int 
     const int wo = (l == 0) ? 0 : WP * 16 + (l - 1) * WP * WP;
     int pidx;
     if (r < (int64_t)in_d * out_d) {   // fragment-native block layout (fused_kernel.h, GradSink)
-      const int row = unit_at((int)(r / in_d), perm && l < n.L), col = unit_at((int)(r % in_d), perm), ntn = inP / 16;
+      const int row = unit_at((int)(r / in_d), row_permuted(flags, l, n.L)), col = unit_at((int)(r % in_d), col_permuted(flags, l)), ntn = inP / 16;
       const int blk = (row >> 4) * ntn + (col >> 4), ln = ((row & 15) >> 2) * 16 + (col & 15);
       pidx = rmajor ? wo + (blk * 4 + (row & 3)) * 64 + ln : wo + (blk * 64 + ln) * 4 + (row & 3);
-    } else pidx = PW + l * WP + unit_at((int)(r - (int64_t)in_d * out_d), perm && l < n.L);
+    } else pidx = PW + l * WP + unit_at((int)(r - (int64_t)in_d * out_d), row_permuted(flags, l, n.L));
     const int per = (copies + 3) / 4;
     const int c0 = grp * per, c1 = (c0 + per < copies) ? c0 + per : copies;
     s = sum_copies(wg, PP, pidx, c0, c1);
@@ -233,7 +239,7 @@ __global__ void k_finish_adam(Net n, int WP, const float* __restrict__ wg, int c
                               int n_loss_rows, const float* __restrict__ loss_rows, float* __restrict__ losses,
                               int row_cols, int flags) {
 #pragma clang fp contract(off)
-  const int perm = flags & 1, rmajor = flags >> 1;
+  const int rmajor = (flags & PACK_RMAJOR) != 0;
   if (blockIdx.x == gridDim.x - 1) {          // loss sums: double, fixed order (k_reduce_sums)
     __shared__ double red[256];
     // [col sums (row_cols of them) | term sums], for the optional weighted losses.  row_cols is the CALLER's column
@@ -280,11 +286,11 @@ __global__ void k_finish_adam(Net n, int WP, const float* __restrict__ wg, int c
     int pidx;
     is_w = r < (int64_t)in_d * out_d;
     if (is_w) {   // fragment-native block layout (fused_kernel.h, GradSink); row / col: PADDED indices from here on
-      row = unit_at((int)(r / in_d), perm && l < n.L); col = unit_at((int)(r % in_d), perm);
+      row = unit_at((int)(r / in_d), row_permuted(flags, l, n.L)); col = unit_at((int)(r % in_d), col_permuted(flags, l));
       const int ntn = inP / 16;
       const int blk = (row >> 4) * ntn + (col >> 4), ln = ((row & 15) >> 2) * 16 + (col & 15);
       pidx = rmajor ? wo + (blk * 4 + (row & 3)) * 64 + ln : wo + (blk * 64 + ln) * 4 + (row & 3);
-    } else { row = unit_at((int)(r - (int64_t)in_d * out_d), perm && l < n.L); pidx = PW + l * WP + row; }
+    } else { row = unit_at((int)(r - (int64_t)in_d * out_d), row_permuted(flags, l, n.L)); pidx = PW + l * WP + row; }
     const int per = (copies + 3) / 4;
     const int c0 = grp * per, c1 = (c0 + per < copies) ? c0 + per : copies;
     s = sum_copies(wg, PP, pidx, c0, c1);
@@ -379,7 +385,19 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
     grid = batch_grid(P.n_tiles, T, batch_occ(g.WP, n.K1));
     P.scratch_per_wave = (int64_t)T * (n.L > 1 ? n.L - 1 : 1) * n.K1 * batch_ks(n) * 64;
   }
-  const int perm = batch ? 1 : 0;   // the batch kernel's k-step-major unit order (fused_batch_kernel.h)
+  // k_fused<64, ..., KRO > 0>: the specialised-epilogue kernels take inputs / outputs in k-step-major order
+  if (!batch && !coop && g.WP == 64 && grad && P.acc_lds && n.act == PINN_ACT_TANH && P.loss_kind == 1 && !Y && P.n_split < 0 &&
+      n.d_in <= 4) {
+    const int rid = P.residual_id;
+    P.io1 = (n.K1 == 4 && rid == PINN_RES_NAVIER_STOKES && n.d_out <= 4) ||
+            (n.K1 == 3 && rid == PINN_RES_PHYSICS_EQUATION && n.d_out <= 8) ||
+            (n.K1 == 3 && (rid == PINN_RES_CONTINUITY_ONLY || rid == PINN_RES_CONTINUITY_FTEMP) && n.d_out <= 4);
+    if (P.io1) {   // the epilogue addresses the output tile / the input jet by PADDED index
+      for (int j = 0; j < PINN_MAX_ROLES; ++j) if (P.out_col[j] >= 0) P.out_col[j] = perm16(P.out_col[j]);
+      for (int j = 0; j < PINN_MAX_DIRS; ++j) if (P.dir_col[j] >= 0) P.dir_col[j] = perm16(P.dir_col[j]);
+    }
+  }
+  const int perm = (batch ? PACK_PERM : 0) | (P.io1 ? PACK_IN | PACK_OUT : 0);   // unit order the pass expects
 
   const AdamReq* adam = rq ? rq->adam : nullptr;
   const int packN = g.PW > g.PB ? g.PW : g.PB;
@@ -411,7 +429,7 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
                        (P.loss_kind & 1) ? rq->n_terms : 0, rq->sums, (P.loss_kind & 2) ? rq->n_cols : 0, rq->mse_sums,
                        rq->grad, adam->params, adam->m, adam->v, (float*)(base + w.wp), (float*)(base + w.wtp),
                        (float*)(base + w.bp), adam->w1, adam->b2, adam->w2, adam->eps, adam->step_size, adam->bc2_sqrt,
-                       adam->n_loss_rows, adam->loss_rows, adam->losses, rq->n_cols, perm | (rmajor << 1));
+                       adam->n_loss_rows, adam->loss_rows, adam->losses, rq->n_cols, perm | (rmajor ? PACK_RMAJOR : 0));
     return check_launch("fused finish + adam");
   }
   if (rq) {
@@ -425,7 +443,7 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
       const int copies = n_copies;
       const int64_t np = n.n_params();
       hipLaunchKernelGGL(k_reduce_grads, dim3((unsigned)((np + 63) / 64)), dim3(256), 0, s, n, g.WP,
-                         (const float*)P.wg_grads, copies, g.PP, g.PW, rq->grad, perm | (rmajor << 1));
+                         (const float*)P.wg_grads, copies, g.PP, g.PW, rq->grad, perm | (rmajor ? PACK_RMAJOR : 0));
     }
   }
   return check_launch("fused reductions");

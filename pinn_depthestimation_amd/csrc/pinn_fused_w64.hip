@@ -15,7 +15,9 @@ static int launch_one_act(const FusedParams& P, int grid, size_t lds, hipStream_
 // residual-only gradient kernels with the epilogue specialised to one residual family (fused_kernel.h, EPI)
 template <int K1, int EPI>
 static int launch_special(const FusedParams& P, int grid, size_t lds, hipStream_t s) {
-  auto kern = k_fused<64, K1, true, true, PINN_ACT_TANH, EPI>;
+  // k-step-major inputs / outputs (fused_kernel.h, KRO): ceil(d_out / 4) k-steps in the output layer's reverse GEMM
+  constexpr int KRO = EPI == EPI_PE ? 2 : 1;
+  auto kern = k_fused<64, K1, true, true, PINN_ACT_TANH, EPI, KRO>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(FUSED_THREADS), lds, s, P);
   return check_launch("fused kernel (WP=64, specialised epilogue)");
@@ -24,7 +26,7 @@ static int launch_special(const FusedParams& P, int grid, size_t lds, hipStream_
 template <int K1, bool GRAD, bool LDSACC>
 static int launch_one(const FusedParams& P, int grid, size_t lds, hipStream_t s) {
   if constexpr (GRAD && LDSACC && K1 >= 3) {
-    if (P.act == PINN_ACT_TANH && P.loss_kind == 1 && P.Y == nullptr && P.n_split < 0) {
+    if (P.io1) {   // (pinn_fused.hip decides: tanh, residual only, no outputs wanted, d_in <= 4, d_out within the epilogue's k-steps)
       if constexpr (K1 == 4) {
         if (P.residual_id == PINN_RES_NAVIER_STOKES) return launch_special<4, EPI_NS>(P, grid, lds, s);
       }

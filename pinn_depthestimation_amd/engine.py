@@ -359,7 +359,7 @@ class Engine:
         ws = self.workspace(N)
         tok = self._packed_tok
         packed_valid = (tok is not None and tok[0] is ws and tok[1] == params.data_ptr() and tok[2] == params._version
-                        and tok[3] == params_token and tok[4] == N)      # (N picks the kernel, and with it the packed layout)
+                        and tok[3] == params_token and tok[4] == (N, int(n_res), nc))     # (the request picks the kernel, and with it the packed layout)
         self._packed_tok = None
         st = _lib.PinnAdamState(_ptr(m), _ptr(v), int(step), 0.0 if lrs is not None else float(lr), float(beta1), float(beta2),
                                 float(eps), 1 if packed_valid else 0, n_rows, _ptr(loss_rows), _ptr(losses))
@@ -376,7 +376,7 @@ class Engine:
         if rc == _lib.ERR_UNSUPPORTED:
             return False
         check(rc, "pinn_loss_grad_adam_step" if lrs is None else "pinn_adam_loop")
-        self._packed_tok = (ws, params.data_ptr(), params._version, params_token, N)
+        self._packed_tok = (ws, params.data_ptr(), params._version, params_token, (N, int(n_res), nc))
         return True
 
     def invalidate_packed(self):

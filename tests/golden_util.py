@@ -1,4 +1,6 @@
-"""Helpers to read tests/golden/*.npz (written by tests/golden/make_goldens.py)."""
+"""Helpers shared by the test modules: reading tests/golden/*.npz (written by tests/golden/make_goldens*.py), the oracle's
+loss + flat gradient for a named residual, and the config dicts several modules train on.  Test modules import from
+here, never from each other (a module's autouse fixtures would ride along)."""
 import os
 
 import numpy as np
@@ -23,3 +25,40 @@ def layers_of(sd):
 def rel_l2(a, b):
     a, b = torch.as_tensor(a).double().reshape(-1), torch.as_tensor(b).double().reshape(-1)
     return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+def oracle_loss_and_grad(params, X, res, inn, outn, gc, dtype):
+    """Loss and flat gradient of residual `res` from the CPU oracle (checker only) in the given dtype."""
+    from oracle import pinn_oracle as O
+    from pinn_depthestimation_amd.engine import RESIDUAL_ROLES
+    _, out_roles, dir_roles = RESIDUAL_ROLES[res]
+    p = [q.to(dtype).clone().requires_grad_(True) for q in params]
+    loss = O.residual_loss(p, X.to(dtype), res, [inn.index(r) for r in dir_roles], [outn.index(r) for r in out_roles], gc)
+    return loss.detach(), O.flat_grad(loss, p)
+
+
+# config_CMB.json's sections as the trainer reads them (train.py:35-36); the file itself does not travel to the GPU box
+CMB = {
+    "layers": {"input_features": 2, "hidden_layers": 10, "hidden_width": 10, "output_features": 6,
+               "dropout_rate": 0.0, "init_type": "xavier"},
+    "adam_optimizer": {"max_it": 50000, "learning_rate": 1e-4, "scheduler_step_size": 10000, "scheduler_gamma": 0.8},
+    "lbfgs_optimizer": {"max_it": 50000, "learning_rate": 1, "max_evaluation": 6.25e4, "history_size": 100,
+                        "tolerance_grad": 1e-5, "tolerance_change": 1e-7, "line_search_fn": "strong_wolfe"},
+    "loss": {"weight_h_loss": 1, "weight_eta_mean_loss": 1, "weight_U_loss": 1, "weight_V_loss": 1,
+             "weight_k_loss": 1, "weight_Hrms_loss": 1, "weight_fid_loss": 1, "weight_res_loss": 1},
+    "data_fidelity": {"inputs": ["x", "y"], "outputs": ["h", "U", "V", "eta_mean", "Hrms", "k"], "training_points": 12},
+    "data_residual": {"inputs": {"x": {"requires_grad": ["true"]}, "y": {"requires_grad": ["true"]}},
+                      "outputs": ["h", "U", "V", "eta_mean", "Hrms", "k"]},
+}
+
+
+def ns_config(adam_it, step=50, lbfgs_it=0):
+    return {
+        "layers": {"input_features": 3, "hidden_layers": 8, "hidden_width": 64, "output_features": 4},
+        "adam_optimizer": {"max_it": adam_it, "learning_rate": 1e-4, "scheduler_step_size": step, "scheduler_gamma": 0.8},
+        "lbfgs_optimizer": {"max_it": lbfgs_it, "learning_rate": 1, "max_evaluation": None, "history_size": 100,
+                            "tolerance_grad": 1e-5, "tolerance_change": 1e-7, "line_search_fn": "strong_wolfe"},
+        "loss": {"weight_fid_loss": 1, "weight_res_loss": 1},
+        "data_fidelity": {"inputs": ["t", "x", "y"], "outputs": []},
+        "data_residual": {"inputs": {k: {"requires_grad": ["true"]} for k in "txy"}, "outputs": ["h", "z", "u", "v"]},
+    }

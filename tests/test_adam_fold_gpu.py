@@ -267,3 +267,22 @@ def test_writes_through_the_modules_parameters_invalidate_the_packed_weights():
     for k, (a, b) in enumerate(zip(out["classic"][1], out["folded"][1])):
         assert torch.equal(a, b), f"loss sums differ at iteration {k + 1}: the pass ran on stale packed weights"
     assert torch.equal(out["classic"][0], out["folded"][0])
+
+
+def test_loss_rows_keep_their_column_stride_when_no_fidelity_point_is_given():
+    """n_res == N with n_cols > 0 runs as a residual-only pass, but loss_rows is (rows, n_cols + n_terms) by
+    the header's contract: the column sums are zeros, the term sums sit BEHIND them (they used to be read with stride
+    n_terms and multiplied by the column weights)."""
+    desc, spec, flat0, X, T, scale, cscale, fid, n_res = _setup("ns8x64_split")
+    P, N = flat0.numel(), X.shape[0]
+    eng = Engine(desc)
+    th, m, v, grad = flat0.clone(), torch.zeros(P, device="cuda"), torch.zeros(P, device="cuda"), torch.zeros(P, device="cuda")
+    ts, cs = torch.zeros(spec.n_terms, device="cuda"), torch.full((len(fid),), 7.0, device="cuda")
+    rows = torch.rand(3, len(fid) + spec.n_terms, generator=torch.Generator().manual_seed(2)).cuda()
+    out = torch.zeros(3, device="cuda")
+    full_scale = torch.full((spec.n_terms,), 1.0 / N, device="cuda")
+    assert eng.loss_grad_adam_step(spec, full_scale, th, X, N, grad, m, v, 1, 1e-3, T=None, out_col=fid, col_scale=cscale,
+                                   term_sums=ts, col_sums=cs, loss_rows=rows, losses=out)
+    assert float(cs.abs().sum()) == 0.0                       # no fidelity point: zero column sums
+    ref = rows[:, len(fid):].double() @ ts.double()
+    assert torch.allclose(out.double(), ref, rtol=1e-6), (out, ref)

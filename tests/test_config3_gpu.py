@@ -6,8 +6,13 @@ Adam steps of the reference in fp32).  Weights come from tests/golden/synth.py (
 Tolerances:
   fp32 mode   loss 3e-6, gradient 3e-5 rel-L2 vs the reference's fp64 run (its own fp32-vs-fp64 noise at this
               shape is 8.7e-8 / 1.6e-7, stored in the fixture); forward 3e-6 abs vs the reference's fp32 Y.
-  bf16 mode   hidden-GEMM operands (weights AND jets) carry 8 significant bits; measured error at 12 x 256 is
-              1.2e-3 (loss) / 1.4e-3 (gradient): asserted 5e-3 / 5e-3, a 4x margin, not the 2e-2 / 5e-2 of round 1.
+  bf16 mode   this is a TOLERANCE, not fp32 parity: the jets between layers carry 8 significant bits (the weights are
+              split hi + lo and multiply exactly).  Measured against the reference's fp64 run at N = 2000:
+              2.8e-3 (loss) / 3.3e-3 (gradient), asserted at 5e-3 / 5e-3 (1.5x to 1.8x of what is measured; the margin
+              covers box-to-box and launch-geometry differences of the summation order, which move the third digit).
+              At 2^21 points, bf16 mode against fp32 mode of the same engine: 3.1e-3 / 3.5e-3, asserted at 5.5e-3
+              (1.55x).  north_star's "loss within 1e-5 rel" is met by the fp32 modes only (G7 / G7b / G10b: 7.8e-6);
+              bf16 mode's trajectory check (G10b) is a descent check — every loss within 25 % (measured 15 %).
 """
 import numpy as np
 import pytest
@@ -123,4 +128,4 @@ def test_config3_full_size_properties():
     el = abs(res[PREC_BF16][0] - res[PREC_F32][0]) / res[PREC_F32][0]
     eg = rel_l2(res[PREC_BF16][1], res[PREC_F32][1])
     print(f"2^21 points: bf16 vs fp32 mode: loss {el:.2e}, grad {eg:.2e}")
-    assert el < 5e-3 and eg < 5e-3
+    assert el < 5.5e-3 and eg < 5.5e-3       # measured 3.1e-3 / 3.5e-3 (module docstring)

@@ -17,22 +17,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "compat"))
 
-from tests.golden_util import layers_of, load, rel_l2, state_dict  # noqa: E402
+from tests.golden_util import CMB, layers_of, load, ns_config, rel_l2, state_dict  # noqa: E402
 
 pytestmark = pytest.mark.gpu
-
-CMB = {
-    "layers": {"input_features": 2, "hidden_layers": 10, "hidden_width": 10, "output_features": 6,
-               "dropout_rate": 0.0, "init_type": "xavier"},
-    "adam_optimizer": {"max_it": 50000, "learning_rate": 1e-4, "scheduler_step_size": 10000, "scheduler_gamma": 0.8},
-    "lbfgs_optimizer": {"max_it": 50000, "learning_rate": 1, "max_evaluation": 6.25e4, "history_size": 100,
-                        "tolerance_grad": 1e-5, "tolerance_change": 1e-7, "line_search_fn": "strong_wolfe"},
-    "loss": {"weight_h_loss": 1, "weight_eta_mean_loss": 1, "weight_U_loss": 1, "weight_V_loss": 1,
-             "weight_k_loss": 1, "weight_Hrms_loss": 1, "weight_fid_loss": 1, "weight_res_loss": 1},
-    "data_fidelity": {"inputs": ["x", "y"], "outputs": ["h", "U", "V", "eta_mean", "Hrms", "k"], "training_points": 12},
-    "data_residual": {"inputs": {"x": {"requires_grad": ["true"]}, "y": {"requires_grad": ["true"]}},
-                      "outputs": ["h", "U", "V", "eta_mean", "Hrms", "k"]},
-}
 
 
 def cols_of(X, grad_cols, device="cuda"):
@@ -143,18 +130,6 @@ def test_g6_trainer_loss_func_config_cmb(tmp_path):
     lines = open(tmp_path / "log.txt").read().splitlines()
     assert lines[0] == "Epoch, Fidelity Loss, Residual Loss, Total Loss"       # train.py:167
     assert lines[1] == f"1, {fid:.5e}, {res:.5e}, {tot:.5e}"
-
-
-def ns_config(adam_it, step=50, lbfgs_it=0):
-    return {
-        "layers": {"input_features": 3, "hidden_layers": 8, "hidden_width": 64, "output_features": 4},
-        "adam_optimizer": {"max_it": adam_it, "learning_rate": 1e-4, "scheduler_step_size": step, "scheduler_gamma": 0.8},
-        "lbfgs_optimizer": {"max_it": lbfgs_it, "learning_rate": 1, "max_evaluation": None, "history_size": 100,
-                            "tolerance_grad": 1e-5, "tolerance_change": 1e-7, "line_search_fn": "strong_wolfe"},
-        "loss": {"weight_fid_loss": 1, "weight_res_loss": 1},
-        "data_fidelity": {"inputs": ["t", "x", "y"], "outputs": []},
-        "data_residual": {"inputs": {k: {"requires_grad": ["true"]} for k in "txy"}, "outputs": ["h", "z", "u", "v"]},
-    }
 
 
 def test_g7_adam_trajectory_200_steps():

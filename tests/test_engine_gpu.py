@@ -12,6 +12,8 @@ from pinn_depthestimation_amd import Engine, NetDesc, ResidualSpec
 from pinn_depthestimation_amd._lib import (ACT_LEAKY_RELU, ACT_TANH, ENGINE_FUSED, ENGINE_FUSED_BATCH, ENGINE_FUSED_COOP,
                                            ENGINE_FUSED_TILE, ENGINE_GENERIC)
 
+from tests.golden_util import oracle_loss_and_grad, rel_l2
+
 pytestmark = pytest.mark.gpu
 
 CASES = {
@@ -43,18 +45,6 @@ def make_case(name, N, seed=1234, dtype=torch.float32):
         params[-1][outn.index("eta_mean")] = 0.0
     X = (torch.rand(N, d_in, generator=g) * 2 - 1)
     return layers, params, X, NetDesc(d_in, d_out, L, W, gc), res, inn, outn
-
-
-def oracle_loss_and_grad(params, X, res, inn, outn, gc, dtype):
-    from pinn_depthestimation_amd.engine import RESIDUAL_ROLES
-    _, out_roles, dir_roles = RESIDUAL_ROLES[res]
-    p = [q.to(dtype).clone().requires_grad_(True) for q in params]
-    loss = O.residual_loss(p, X.to(dtype), res, [inn.index(r) for r in dir_roles], [outn.index(r) for r in out_roles], gc)
-    return loss.detach(), O.flat_grad(loss, p)
-
-
-def rel_l2(a, b):
-    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
 
 ENGINES = [ENGINE_GENERIC, ENGINE_FUSED]

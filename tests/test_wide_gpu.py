@@ -6,7 +6,7 @@ import torch
 from oracle import pinn_oracle as O
 from pinn_depthestimation_amd import Engine, NetDesc, ResidualSpec
 from pinn_depthestimation_amd._lib import ENGINE_GENERIC, ENGINE_WIDE
-from tests.test_engine_gpu import oracle_loss_and_grad, rel_l2
+from tests.golden_util import oracle_loss_and_grad, rel_l2
 
 pytestmark = pytest.mark.gpu
 

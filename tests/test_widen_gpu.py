@@ -12,8 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "compat"))
 
 from oracle import pinn_oracle as O  # noqa: E402
-from tests.golden_util import layers_of, load, rel_l2, state_dict  # noqa: E402
-from tests.test_dropin_gpu import CMB, ns_config  # noqa: E402
+from tests.golden_util import CMB, layers_of, load, ns_config, rel_l2, state_dict  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -264,7 +263,6 @@ def test_dropout_training_mode_matches_oracle_with_the_engines_mask(shape, p):
     engine's mask is a pure function of (seed, layer, unit, point): the same mask (tests/dropout_util.py) handed to
     the oracle must give the same outputs, input derivatives, loss and parameter gradient."""
     from tests.dropout_util import keep_masks
-    from tests.test_engine_gpu import rel_l2
     _, d_in, d_out, L, W, gc, res, inn, outn = shape
     N, seed = 333, 20241004
     g = torch.Generator().manual_seed(17)

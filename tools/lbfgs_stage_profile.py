@@ -1,0 +1,31 @@
+"""lbfgs_stage_profile.py: where the wall time of the L-BFGS stage at N = 2^20 goes (cProfile of one LBFGS.step)."""
+import cProfile, pstats, os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from pinn_depthestimation_amd.trainer import PINN
+N = 1 << 20
+cfg = {"layers": {"input_features": 3, "hidden_layers": 8, "hidden_width": 64, "output_features": 4},
+       "adam_optimizer": {"max_it": 50, "learning_rate": 1e-4, "scheduler_step_size": 10000, "scheduler_gamma": 0.8},
+       "lbfgs_optimizer": {"max_it": 15, "learning_rate": 1, "max_evaluation": None, "history_size": 100,
+                           "tolerance_grad": 0.0, "tolerance_change": 0.0, "line_search_fn": "strong_wolfe"},
+       "loss": {"weight_fid_loss": 1, "weight_res_loss": 1},
+       "data_fidelity": {"inputs": ["t", "x", "y"], "outputs": []},
+       "data_residual": {"inputs": {k: {"requires_grad": ["true"]} for k in "txy"}, "outputs": ["h", "z", "u", "v"]}}
+X = (torch.rand(N, 3, generator=torch.Generator().manual_seed(1234)) * 2 - 1).numpy()
+for rep in range(2):
+    torch.manual_seed(1234)
+    tr = PINN(None, None, X, cfg, log_every=1000, checkpoint_every=0)
+    tr.train_adam(50)
+    torch.cuda.synchronize()
+    t_sync = []
+    orig = tr.closure
+    def timed():
+        t0 = time.perf_counter(); l = orig(); torch.cuda.synchronize(); t_sync.append(time.perf_counter() - t0); return l
+    pr = cProfile.Profile()
+    t0 = time.perf_counter()
+    pr.enable(); tr.optimizer_LBFGS.step(timed); pr.disable()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"rep {rep}: step {dt*1e3:.1f} ms, {len(t_sync)} closures, in closures (synced) {sum(t_sync)*1e3:.1f} ms; per closure {[round(x*1e3,1) for x in t_sync]}")
+    if rep == 1:
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
