@@ -42,7 +42,7 @@ PTS_PER_GPU = 1 << 20
 # HBM bytes per point from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 on
 # gfx950 + WRITE_SIZE), keyed by (workload, bf16)
 PMC_SUMMARIES = {
-    ("ns8x64", False): ("profiles/r02/fused_r02_pmc_summary.json", "hbm_bytes_per_point"),
+    ("ns8x64", False): ("profiles/r03/fused_r03_pmc_summary.json", "hbm_bytes_per_point"),
     ("pe10x10", False): ("profiles/r03/pe10x10_batch_pmc_summary.json", "hbm_bytes_per_point"),
     ("co100x20", False): ("profiles/r03/co100x20_batch_pmc_summary.json", "hbm_bytes_per_point"),
     ("ns12x256", True): ("profiles/r02/wide_bf16_pmc_summary.json", "hbm_bytes_per_point"),

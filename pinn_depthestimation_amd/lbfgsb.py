@@ -25,19 +25,49 @@ class LBFGSBOptimizer:
             self.options.update(options)
         self.losses = []
 
+    def _staging(self, P: int, device):
+        """Pinned host buffers, allocated once: x (fp32) on its way in, [gradient | loss] on its way out.  With pageable
+        memory every evaluation paid three blocking copies (x in, float(loss), gradient out: 25 ms around a 6.5 ms
+        closure at N = 2^20, tools/lbfgs_stage_profile.py); pinned and asynchronous it is ONE synchronisation."""
+        st = getattr(self, "_stage", None)
+        if st is None or st[0].numel() != P:
+            pin = device.type == "cuda"
+            st = (torch.empty(P, dtype=torch.float32, pin_memory=pin), torch.empty(P + 1, dtype=torch.float32, pin_memory=pin))
+            self._stage = st
+        return st
+
     def function_for_scipy(self, x: np.ndarray):
         """flat float64 vector -> (loss, flat float64 gradient); one closure evaluation."""
         tr = self.trainer
         theta = tr.dnn.flat_params()
-        theta.copy_(torch.from_numpy(np.asarray(x, dtype=np.float64)).to(theta.device, torch.float32))
+        P = theta.numel()
+        x32, out = self._staging(P, theta.device)
+        x32.copy_(torch.from_numpy(np.asarray(x, dtype=np.float64)))          # fp64 -> fp32 on the host, into pinned memory
+        theta.copy_(x32, non_blocking=True)
         loss = tr.loss_func()
-        self.losses.append(float(loss))
-        return float(loss), tr.grad.detach().to("cpu", torch.float64).numpy().copy()
+        out[:P].copy_(tr.grad.detach(), non_blocking=True)
+        out[P:].copy_(loss.detach().reshape(1), non_blocking=True)
+        if theta.is_cuda:
+            torch.cuda.current_stream(theta.device).synchronize()
+        f = float(out[P])
+        self.losses.append(f)
+        return f, out[:P].double().numpy().copy()
 
     def minimize(self):
         from scipy.optimize import minimize
         x0 = self.trainer.dnn.flat_params().detach().to("cpu", torch.float64).numpy()
-        res = minimize(self.function_for_scipy, x0, jac=True, method="L-BFGS-B", options=self.options)
+        # SciPy's L-BFGS-B does its level-1 BLAS on P-vectors through OpenBLAS, whose pool sizes itself by the HOST's
+        # core count (64 threads on the MI355X boxes, 16 cores granted): its spinning workers stalled every third
+        # evaluation for ~80 ms (tools/scipy_probe3.py: 18 evaluations in 1034 ms, 135 ms with the pool limited to one
+        # thread — 30 k-element dot products gain nothing from threads)
+        try:
+            from threadpoolctl import threadpool_limits
+            limit = threadpool_limits(limits=1, user_api="blas")
+        except Exception:          # pragma: no cover  (threadpoolctl absent: run as is)
+            import contextlib
+            limit = contextlib.nullcontext()
+        with limit:
+            res = minimize(self.function_for_scipy, x0, jac=True, method="L-BFGS-B", options=self.options)
         self.function_for_scipy(res.x)      # leave the best point in the network
         self.trainer.flush_log()
         return res

@@ -29,3 +29,18 @@ for rep in range(2):
     print(f"rep {rep}: step {dt*1e3:.1f} ms, {len(t_sync)} closures, in closures (synced) {sum(t_sync)*1e3:.1f} ms; per closure {[round(x*1e3,1) for x in t_sync]}")
     if rep == 1:
         pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+
+# the SciPy driver (lbfgsb.LBFGSBOptimizer), second run profiled
+from pinn_depthestimation_amd.lbfgsb import LBFGSBOptimizer
+for rep in range(2):
+    torch.manual_seed(1234)
+    tr = PINN(None, None, X, cfg, log_every=1000, checkpoint_every=0)
+    tr.train_adam(50)
+    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    t0 = time.perf_counter()
+    pr.enable(); LBFGSBOptimizer(tr, {"maxiter": 15, "maxfun": 150, "ftol": 0.0, "gtol": 0.0}).minimize(); pr.disable()
+    dt = time.perf_counter() - t0
+    print(f"scipy rep {rep}: {dt*1e3:.1f} ms")
+    if rep == 1:
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
