@@ -31,6 +31,12 @@ CASES = {
     # deep and narrow (three of the reference's four configs are 20-100 layers of width 20): the padded
     # gradient no longer fits LDS and is accumulated in per-workgroup global copies
     "cf_40x20": (2, 3, 40, 20, (0, 1), "continuity_ftemp", ("x", "y"), ("U", "V", "h")),
+    # corners of the batch kernel's instance table (fused_batch_kernel.h): k = 3 at width <= 16 (two tiles per batch),
+    # four k-steps at width 16, eight at width 32, a single hidden layer (no hidden-to-hidden matrix at all)
+    "ns_3x12": (3, 4, 3, 12, (0, 1, 2), "Navier_Stokes", ("t", "x", "y"), ("h", "z", "u", "v")),
+    "pe_2x16": (2, 6, 2, 16, (0, 1), "physics_equation", ("x", "y"), ("h", "U", "V", "eta_mean", "Hrms", "k")),
+    "cf_3x32": (2, 3, 3, 32, (0, 1), "continuity_ftemp", ("x", "y"), ("U", "V", "h")),
+    "pe_1x10": (2, 6, 1, 10, (0, 1), "physics_equation", ("x", "y"), ("h", "U", "V", "eta_mean", "Hrms", "k")),
 }
 
 
