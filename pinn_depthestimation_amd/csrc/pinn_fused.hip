@@ -66,6 +66,7 @@ int batch_T_for(const Geo& g, int K1, int64_t n_tiles) {
   return n_tiles >= (int64_t)cu_count() * BATCH_WAVES * batch_occ(g.WP, K1) * T ? T : 1;
 }
 int64_t batch_lds_fixed_bytes(int WP, int K1) { return (int64_t)(BATCH_WAVES * batch_pads(WP, K1) * TB_FLOATS + BATCH_WAVES * MAX_SUMS) * 4; }
+int64_t batch_lds_comb_bytes(int WP) { return (int64_t)batch_comb_floats(WP) * 4; }   // T = 1 + atomic sink: bwgrad_flush_wg's two buffers
 int batch_ks(const Net& n) { return n.W <= 12 ? 3 : (n.W <= 16 ? 4 : (n.W <= 20 ? 5 : 8)); }   // k-steps of the kernel instance
 int batch_grid(int64_t n_tiles, int T, int occ) {
   const int64_t nb = (n_tiles + T - 1) / T;
@@ -368,7 +369,8 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
     P.acc_lds = ((int64_t)BATCH_WAVES * g.PP * 4 + batch_lds_fixed_bytes(g.WP, n.K1)) * batch_occ(g.WP, n.K1) <= LDS_LIMIT ? 1 : 0;
     P.lds_acc_floats = P.acc_lds ? BATCH_WAVES * g.PP : 0;
   }
-  const size_t lds = batch ? (size_t)P.lds_acc_floats * 4 + (size_t)batch_lds_fixed_bytes(g.WP, n.K1)
+  const size_t lds = batch ? (size_t)P.lds_acc_floats * 4 + (size_t)batch_lds_fixed_bytes(g.WP, n.K1) +
+                                 (size_t)(!P.acc_lds && batch_T_for(g, n.K1, P.n_tiles) == 1 ? batch_lds_comb_bytes(g.WP) : 0)
                    : coop ? (size_t)coop_lds_bytes(n, g, grad) : (size_t)P.lds_acc_floats * 4 + (size_t)lds_fixed_bytes();
   // 8x64 gradient kernels fill the register file and most of LDS (1 workgroup per CU); the narrow
   // networks' kernels fit 2 waves per SIMD, which hides their per-layer latencies
