@@ -99,7 +99,9 @@ typedef struct pinn_desc {
    * hidden layer l at point n is a pure function of (dropout_seed, l, f, n) — pinn_dropout_keep below — so a
    * forward call and the reverse sweep that follows it (same seed) see the same mask without storing it; the caller
    * draws a new seed per forward pass.  Kept units are scaled by 1 / (1 - p), tangents included.
-   * Runs on the generic engine (AUTO selects it; FUSED / WIDE with dropout_p > 0 are refused). */
+   * Gradient passes of tanh networks of hidden width 33..64 run on the fused tile kernel's dropout instances (the mask
+   * re-derived in registers); every other call with dropout_p > 0 runs on the generic engine.  AUTO picks accordingly;
+   * FUSED is refused for requests it does not serve, WIDE always. */
   float dropout_p;
   uint32_t dropout_seed;
 } pinn_desc;

@@ -89,6 +89,8 @@ struct FusedParams {
   int lds_acc_floats;        // floats reserved for the LDS gradient copy (0 if unused)
   int batch_T;               // k_fused_batch: tiles per wave and batch of the instance to launch
   int io1;                   // k_fused<..., IO1 = true>: inputs / outputs in k-step-major order (see k_fused)
+  uint32_t drop_seed, drop_thresh;   // k_fused<..., DROP = true>: nn.Dropout in training mode (common.h: dropout_bits)
+  float drop_scale, drop_keep;       // 1 / (1 - p), 1 - p
 };
 
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
@@ -237,6 +239,24 @@ __device__ __forceinline__ void activate_adjoint(f4 (&G)[K1][NT], const f4 (&A)[
 }
 
 
+// nn.Dropout(p) after every hidden activation in training mode (dnn.py:36-38, train.py:186), fused: the keep mask is
+// the counter-based hash of common.h (dropout_bits(seed, layer, unit, point)), re-derived lane-locally wherever it is
+// needed — in the activation and again in its adjoint — so nothing is stored.  The point's part of the hash is formed
+// once per tile (DropLane), the (layer, unit) part per register.
+struct DropLane {
+  uint32_t h0, hi, thresh;
+  float scale, keep_p;
+  __device__ __forceinline__ void init(uint32_t seed, uint32_t thr, float sc, float kp, int64_t point) {
+    h0 = dropout_fmix(seed ^ ((uint32_t)point * 0x9E3779B1u));
+    hi = (uint32_t)((uint64_t)point >> 32);
+    thresh = thr; scale = sc; keep_p = kp;
+  }
+  __device__ __forceinline__ float mask(int layer, int unit) const {     // 1 / (1 - p) for a kept unit, 0 for a dropped one
+    const uint32_t x = h0 ^ (((uint32_t)layer * 0x01000193u + (uint32_t)unit) * 0x9E3779B1u + hi);
+    return dropout_fmix(x) >= thresh ? scale : 0.f;
+  }
+};
+
 // out-of-place forms: read the accumulators, write the next GEMM's B operand / the layer adjoint
 // The bias is added here rather than used as the accumulators' initial value: its load is issued
 // before the GEMM and consumed after it (as an initial value its L2 latency sat exposed in front of
@@ -246,8 +266,9 @@ __device__ __forceinline__ void load_bias(const float* __restrict__ b, f4 (&bias
 #pragma unroll
   for (int MT = 0; MT < NT; ++MT) bias[MT] = *reinterpret_cast<const f4*>(b + 16 * MT + 4 * q);
 }
-template <int ACT, int NT, int K1>
-__device__ __forceinline__ void activate_to(const f4 (&acc)[K1][NT], const f4 (&bias)[NT], f4 (&a)[K1][NT]) {
+template <int ACT, int NT, int K1, bool DROP = false>
+__device__ __forceinline__ void activate_to(const f4 (&acc)[K1][NT], const f4 (&bias)[NT], f4 (&a)[K1][NT],
+                                            const DropLane* dl = nullptr, int layer = 0, int q = 0) {
 #pragma unroll
   for (int MT = 0; MT < NT; ++MT)
 #pragma unroll
@@ -256,20 +277,30 @@ __device__ __forceinline__ void activate_to(const f4 (&acc)[K1][NT], const f4 (&
       float av, s;
       if constexpr (ACT == PINN_ACT_TANH) { av = tanh_f32(z); s = fmaf(-av, av, 1.f); }
       else { av = z > 0.f ? z : 0.01f * z; s = z > 0.f ? 1.f : 0.01f; }
+      if constexpr (DROP) {      // a <- m a / (1 - p): the same mask multiplies the value and its tangents
+        const float m = dl->mask(layer, 16 * MT + 4 * q + r);
+        av *= m; s *= m;
+      }
       a[0][MT][r] = av;
 #pragma unroll
       for (int c = 1; c < K1; ++c) a[c][MT][r] = acc[c][MT][r] * s;
     }
 }
-template <int ACT, int NT, int K1>
-__device__ __forceinline__ void activate_adjoint_to(const f4 (&G)[K1][NT], const f4 (&A)[K1][NT], f4 (&Z)[K1][NT]) {
+// DROP: the stored jet is the masked one (a_out = m t, adot_out = m t' zdot with m = mask / (1 - p)); then
+// d a_out / dz = m t', d adot_out / dz = -2 t adot_out and d adot_out / dzdot = m t': the formulas below with
+// a := t = a_out (1 - p) and s := m t' (pinn_generic.hip, k_bwd_layer).  A dropped unit has a_out = adot_out = 0, s = 0.
+template <int ACT, int NT, int K1, bool DROP = false>
+__device__ __forceinline__ void activate_adjoint_to(const f4 (&G)[K1][NT], const f4 (&A)[K1][NT], f4 (&Z)[K1][NT],
+                                                    const DropLane* dl = nullptr, int layer = 0, int q = 0) {
 #pragma unroll
   for (int MT = 0; MT < NT; ++MT)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float a = A[0][MT][r];
+      float a = A[0][MT][r];
+      if constexpr (DROP) a *= dl->keep_p;
       if constexpr (ACT == PINN_ACT_TANH) {
-        const float s = fmaf(-a, a, 1.f);
+        float s = fmaf(-a, a, 1.f);
+        if constexpr (DROP) s *= dl->mask(layer, 16 * MT + 4 * q + r);
         float cross = 0.f;
 #pragma unroll
         for (int c = 1; c < K1; ++c) {
@@ -693,8 +724,9 @@ __device__ __forceinline__ void loss_epilogue(const FusedParams& P, const f4 (&o
 // GEMM KRO = ceil(d_out / 4) k-steps (Navier-Stokes 3 -> 8x64 -> 4: 96 of the tile's 5696 MFMAs gone).  The packing
 // kernels place the weights accordingly (pinn_fused.hip, PACK_IN / PACK_OUT) and the host hands the epilogue PADDED row
 // indices in out_col / dir_col, so the epilogue code is the same.
-template <int WP, int K1, bool GRAD, bool LDSACC, int ACT, int EPI = EPI_GENERIC, int KRO = 0>
+template <int WP, int K1, bool GRAD, bool LDSACC, int ACT, int EPI = EPI_GENERIC, int KRO = 0, bool DROP = false>
 __global__ __launch_bounds__(FUSED_THREADS, WP == 16 ? PINN_FUSED_W16_WAVES : FUSED_WAVES / 4) void k_fused(const FusedParams P) {
+  static_assert(!DROP || (ACT == PINN_ACT_TANH && KRO == 0), "dropout instances: tanh, natural unit order");
   constexpr bool IO1 = KRO > 0;
   constexpr int KRI = IO1 ? 1 : 4;          // k-steps of the first layer's contraction (d_in <= 4 when IO1)
   constexpr int KRL = IO1 ? KRO : 4;        // k-steps of the output layer's reverse contraction
@@ -754,6 +786,8 @@ __global__ __launch_bounds__(FUSED_THREADS, WP == 16 ? PINN_FUSED_W16_WAVES : FU
     const int64_t pt = tile * 16 + p;
     const bool valid = pt < P.N;
     const int64_t ptc = valid ? pt : P.N - 1;
+    DropLane dl;
+    if constexpr (DROP) dl.init(P.drop_seed, P.drop_thresh, P.drop_scale, P.drop_keep, pt);
 #if PINN_FUSED_XPREF
     const f4 xcur = xnext;
     load_x(tile + nw < P.n_tiles ? tile + nw : tile, xnext);
@@ -789,7 +823,7 @@ __global__ __launch_bounds__(FUSED_THREADS, WP == 16 ? PINN_FUSED_W16_WAVES : FU
       zero_tiles<NTH, K1>(acc0);
       gemm_chain<1, NTH, K1, KRI>(w0, b0, acc0);
       PINN_STAMP(0);
-      activate_to<ACT, NTH, K1>(acc0, bias, a);
+      activate_to<ACT, NTH, K1, DROP>(acc0, bias, a, &dl, 0, q);
     }
 #if !PINN_FUSED_MID_IO
     if (GRAD && L > 1) spill<NTH, K1>(scr, a, lane);      // a_L itself stays in registers for the reverse sweep
@@ -805,11 +839,11 @@ __global__ __launch_bounds__(FUSED_THREADS, WP == 16 ? PINN_FUSED_W16_WAVES : FU
       auto sp = [&]() { if (GRAD) spill<NTH, K1>(scr + (l - 1) * SLOT, a, lane); };
       gemm_stream<NTH, NTH, K1>(Wp_ + w_off_p<WP>(l), Wp_ + w_off_p<WP>(l + 1), ws, a, nx, p, q, sp);
       PINN_STAMP(0);
-      activate_to<ACT, NTH, K1>(nx, bias, a);
+      activate_to<ACT, NTH, K1, DROP>(nx, bias, a, &dl, l, q);
 #else
       gemm_stream<NTH, NTH, K1>(Wp_ + w_off_p<WP>(l), Wp_ + w_off_p<WP>(l + 1), ws, a, nx, p, q);
       PINN_STAMP(0);
-      activate_to<ACT, NTH, K1>(nx, bias, a);
+      activate_to<ACT, NTH, K1, DROP>(nx, bias, a, &dl, l, q);
       if (GRAD && l < L - 1) spill<NTH, K1>(scr + l * SLOT, a, lane);   // (the last hidden jet is never re-read)
 #endif
       PINN_STAMP(1);
@@ -851,7 +885,7 @@ __global__ __launch_bounds__(FUSED_THREADS, WP == 16 ? PINN_FUSED_W16_WAVES : FU
         f4 g[K1][NTH];
         zero_tiles<NTH, K1>(g);
         gemm_chain<1, NTH, K1, KRL>(wtl, G, g);
-        activate_adjoint_to<ACT, NTH, K1>(g, a, z);
+        activate_adjoint_to<ACT, NTH, K1, DROP>(g, a, z, &dl, L - 1, q);
       }
       for (int l = L - 1; l >= 1; --l) {
         PINN_STAMP(3);
@@ -867,7 +901,7 @@ __global__ __launch_bounds__(FUSED_THREADS, WP == 16 ? PINN_FUSED_W16_WAVES : FU
         PINN_STAMP(6);
 #if PINN_FUSED_ADJ_IN_FLUSH
         f4 zn[K1][NTH];
-        auto adj = [&]() { activate_adjoint_to<ACT, NTH, K1>(g2, ai, zn); };
+        auto adj = [&]() { activate_adjoint_to<ACT, NTH, K1, DROP>(g2, ai, zn, &dl, l - 1, q); };
         weight_grad<NTH, NTH, K1>(sink, l, w_off_p<WP>(l), P.PW + b_off_p<WP>(l), z, ai, tb, lane, adj);
         copy_tiles<NTH, K1>(z, zn);
 #if !PINN_FUSED_MID_IO
@@ -876,7 +910,7 @@ __global__ __launch_bounds__(FUSED_THREADS, WP == 16 ? PINN_FUSED_W16_WAVES : FU
 #else
         weight_grad<NTH, NTH, K1>(sink, l, w_off_p<WP>(l), P.PW + b_off_p<WP>(l), z, ai, tb, lane);
         PINN_STAMP(5);
-        activate_adjoint_to<ACT, NTH, K1>(g2, ai, z);
+        activate_adjoint_to<ACT, NTH, K1, DROP>(g2, ai, z, &dl, l - 1, q);
 #if !PINN_FUSED_MID_IO
         if (l >= 2) unspill<NTH, K1>(scr + (l - 2) * SLOT, ai, lane);            // a_{l-1}
 #endif

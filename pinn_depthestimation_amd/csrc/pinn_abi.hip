@@ -95,13 +95,19 @@ int make_net(const pinn_desc* d, Net* n) {
 static int pick_engine(const pinn_desc* d, const Net& n, bool want_grad, int* rc) {
   *rc = PINN_OK;
   const int asked = (d->engine == PINN_ENGINE_FUSED_TILE || d->engine == PINN_ENGINE_FUSED_COOP || d->engine == PINN_ENGINE_FUSED_BATCH) ? PINN_ENGINE_FUSED : d->engine;
-  if (n.drop_p > 0.f) {     // training-mode dropout lives in the generic engine's kernels
-    if (asked != PINN_ENGINE_AUTO && asked != PINN_ENGINE_GENERIC) {
+  if (n.drop_p > 0.f) {     // training-mode dropout: the fused tile kernel for gradient passes at padded width 64
+                            // (pinn_fused_w64_drop.hip), the generic engine's kernels for everything else
+    if (n.prec != PINN_PREC_F32) { set_error("dropout_p > 0 is implemented in fp32 only"); *rc = PINN_ERR_UNSUPPORTED; return PINN_ENGINE_GENERIC; }
+    const bool fused_ok = fused_supports(n, want_grad);
+    if (asked == PINN_ENGINE_FUSED && !fused_ok) {
+      set_error("dropout_p > 0 on the fused engine: gradient passes of tanh networks of hidden width 33..64 only; this request "
+                "runs on the generic engine (engine AUTO or GENERIC)");
+      *rc = PINN_ERR_UNSUPPORTED;
+    } else if (asked == PINN_ENGINE_WIDE) {
       set_error("dropout_p > 0 runs on the generic engine (engine AUTO or GENERIC), not on engine %d", d->engine);
       *rc = PINN_ERR_UNSUPPORTED;
     }
-    if (n.prec != PINN_PREC_F32) { set_error("dropout_p > 0 is implemented in fp32 only"); *rc = PINN_ERR_UNSUPPORTED; }
-    return PINN_ENGINE_GENERIC;
+    return (asked == PINN_ENGINE_AUTO || asked == PINN_ENGINE_FUSED) && fused_ok ? PINN_ENGINE_FUSED : PINN_ENGINE_GENERIC;
   }
   if (n.prec == PINN_PREC_BF16) {   // bf16 operands exist on the wide engine only
     if ((asked != PINN_ENGINE_AUTO && asked != PINN_ENGINE_WIDE) || !wide_supports(n)) {
@@ -206,11 +212,12 @@ int32_t pinn_query_workspace(const pinn_desc* desc, int64_t N, int64_t* bytes) {
     return e == PINN_ENGINE_FUSED ? fused_workspace_bytes(n, N)
          : e == PINN_ENGINE_WIDE ? wide_workspace_bytes(n, N) : generic_workspace_bytes(n, N);
   };
-  const int e = pick_engine(desc, n, false, &rc); if (rc) return rc;
-  int64_t b = ws_of(e);
   int rc2 = PINN_OK;
+  const int e = pick_engine(desc, n, false, &rc);
   const int eg = pick_engine(desc, n, true, &rc2);
-  if (rc2 == PINN_OK && eg != e) { const int64_t bg = ws_of(eg); if (bg > b) b = bg; }
+  if (rc && rc2) return rc;                       // neither kind of call is served on the engine asked for
+  int64_t b = rc ? -1 : ws_of(e);
+  if (rc2 == PINN_OK && (rc || eg != e)) { const int64_t bg = ws_of(eg); if (bg > b) b = bg; }
   if (b < 0) { set_error("network not supported"); return PINN_ERR_UNSUPPORTED; }
   *bytes = b;
   return PINN_OK;

@@ -6,6 +6,8 @@
 
 namespace pinn {
 
+int launch_fused_drop64(int K1, const FusedParams& P, int grid, size_t lds, hipStream_t s);   // pinn_fused_w64_drop.hip
+
 namespace {
 
 int padded_width(int W) { return W <= 16 ? 16 : (W <= 32 ? 32 : 64); }
@@ -40,7 +42,7 @@ int64_t coop_lds_bytes(const Net& n, const Geo& g, bool grad) {
 }
 bool use_coop(const Net& n, const Geo& g, bool grad, int64_t N) {
   const int forced = n.fused_kernel == FUSED_KERNEL_COOP ? 1 : (n.fused_kernel == FUSED_KERNEL_TILE ? 0 : -1);
-  if (forced == 0 || g.WP != 64) return false;
+  if (forced == 0 || g.WP != 64 || n.drop_p > 0.f) return false;
   if (coop_lds_bytes(n, g, grad) > LDS_LIMIT) return false;
   if (forced == 1) return true;
   return (N + 15) / 16 <= (int64_t)cu_count();
@@ -50,7 +52,7 @@ bool use_coop(const Net& n, const Geo& g, bool grad, int64_t N) {
 // gets at least one full batch of FUSED_BATCH_T tiles.  desc.engine = PINN_ENGINE_FUSED_BATCH forces it at any N
 // (ragged batches are handled: tiles past the end are computed on a clamped point and contribute nothing).
 bool batch_supported(const Net& n, const Geo& g) {
-  return g.WP <= 32 && n.L >= 1 && n.L + 1 <= MAX_LOCKS && fused_batch_has_kernel(g.WP, n.W, n.d_in, n.K1, n.act);
+  return n.drop_p == 0.f && g.WP <= 32 && n.L >= 1 && n.L + 1 <= MAX_LOCKS && fused_batch_has_kernel(g.WP, n.W, n.d_in, n.K1, n.act);
 }
 constexpr int64_t BATCH_MIN_TILES = 256;   // AUTO: below this many tiles (4096 points) the tile kernel keeps the request
 bool use_batch(const Net& n, const Geo& g, bool grad, int64_t N) {
@@ -388,7 +390,7 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
     P.scratch_per_wave = (int64_t)T * (n.L > 1 ? n.L - 1 : 1) * n.K1 * batch_ks(n) * 64;
   }
   // k_fused<64, ..., KRO > 0>: the specialised-epilogue kernels take inputs / outputs in k-step-major order
-  if (!batch && !coop && g.WP == 64 && grad && P.acc_lds && n.act == PINN_ACT_TANH && P.loss_kind == 1 && !Y && P.n_split < 0 &&
+  if (!batch && !coop && n.drop_p == 0.f && g.WP == 64 && grad && P.acc_lds && n.act == PINN_ACT_TANH && P.loss_kind == 1 && !Y && P.n_split < 0 &&
       n.d_in <= 4) {
     const int rid = P.residual_id;
     P.io1 = (n.K1 == 4 && rid == PINN_RES_NAVIER_STOKES && n.d_out <= 4) ||
@@ -415,7 +417,12 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
     }
   }
   int rc;
-  if (batch) rc = g.WP == 16 ? launch_fused_batch<16>(n.W, n.d_in, n.K1, P, grid, lds, s)
+  if (n.drop_p > 0.f) {     // training-mode dropout: its own instances of the tile kernel (pinn_fused_w64_drop.hip)
+    P.drop_seed = n.drop_seed; P.drop_thresh = n.drop_thresh; P.drop_scale = 1.f / (1.f - n.drop_p); P.drop_keep = 1.f - n.drop_p;
+    if (!(grad && g.WP == 64 && P.acc_lds && n.act == PINN_ACT_TANH)) { set_error("fused engine: no dropout kernel for this request"); return PINN_ERR_UNSUPPORTED; }
+    rc = launch_fused_drop64(n.K1, P, grid, lds, s);
+  }
+  else if (batch) rc = g.WP == 16 ? launch_fused_batch<16>(n.W, n.d_in, n.K1, P, grid, lds, s)
                              : launch_fused_batch<32>(n.W, n.d_in, n.K1, P, grid, lds, s);
   else if (coop) rc = launch_fused_coop(n.K1, grad, P, grid, lds, s);
   else switch (g.WP) {
@@ -468,6 +475,11 @@ bool fused_batch_has_kernel(int WP, int W, int d_in, int K1, int act) {
 
 bool fused_supports(const Net& n, bool want_grad) {
   if (n.L + 1 > MAX_LOCKS) return false;
+  if (n.drop_p > 0.f) {   // dropout: gradient passes of tanh networks of padded width 64 whose gradient copy fits LDS
+    if (!(want_grad && padded_width(n.W) == 64 && n.act == PINN_ACT_TANH && fits_lds(geo_of(n)) && n.fused_kernel != FUSED_KERNEL_COOP &&
+          (n.K1 == 1 || n.K1 == 3 || n.K1 == 4)))
+      return false;
+  }
   if (want_grad && n.K1 == 2) return false;   // no k = 1 gradient kernels (no residual of the reference has one direction)
   if (n.fused_kernel == FUSED_KERNEL_COOP && padded_width(n.W) != 64) return false;
   return n.W <= 64 && n.d_in <= 16 && n.d_out <= 16 && n.L >= 1 && n.K1 >= 1 && n.K1 <= 4;
@@ -484,7 +496,7 @@ bool fused_supports_adam(const Net& n, const LossReq& rq, int64_t N) {
 }
 
 int64_t fused_workspace_bytes(const Net& n, int64_t N) {
-  if (!fused_supports(n, false)) return -1;
+  if (!fused_supports(n, false) && !fused_supports(n, true)) return -1;   // (dropout: gradient passes only)
   return ws_layout(n, geo_of(n), N > 0 ? N : 1).total;
 }
 

@@ -261,7 +261,9 @@ def test_lbfgs_device_recursion_matches_torch_formulation():
 def test_dropout_training_mode_matches_oracle_with_the_engines_mask(shape, p):
     """nn.Dropout(p > 0) after every activation in training mode (dnn.py:38, train.py:186).  The
     engine's mask is a pure function of (seed, layer, unit, point): the same mask (tests/dropout_util.py) handed to
-    the oracle must give the same outputs, input derivatives, loss and parameter gradient."""
+    the oracle must give the same outputs, input derivatives, loss and parameter gradient.  Forward / jet calls run on
+    the generic engine's kernels; the loss + gradient call on the generic engine AND, at padded width 64, on the fused
+    tile kernel's dropout instances (k_fused<..., DROP>: the mask re-derived lane-locally in activation and adjoint)."""
     from tests.dropout_util import keep_masks
     _, d_in, d_out, L, W, gc, res, inn, outn = shape
     N, seed = 333, 20241004
@@ -302,6 +304,19 @@ def test_dropout_training_mode_matches_oracle_with_the_engines_mask(shape, p):
     print(f"dropout p={p} {res}: loss err {el:.2e} (oracle fp32 {noise_l:.1e}), grad err {eg:.2e} (oracle fp32 {noise_g:.1e})")
     assert el < max(5e-6, 4 * noise_l)
     assert eg < max(3e-5, 4 * noise_g)
+    # the same request on each engine that serves it: generic always; fused (tile kernel, DROP instances) at width 33..64
+    from pinn_depthestimation_amd._lib import ENGINE_FUSED, ENGINE_GENERIC
+    for e in (ENGINE_GENERIC, ENGINE_FUSED):
+        g2 = torch.zeros(desc.n_params, device="cuda")
+        if e == ENGINE_FUSED and not 32 < W <= 64:
+            with pytest.raises(Exception, match="fused engine"):
+                eng.residual_loss_grad(spec, scale, flat, Xd, g2, engine=e)
+            continue
+        s2 = eng.residual_loss_grad(spec, scale, flat, Xd, g2, engine=e)
+        l2 = float((s2.double() * scale.double()).sum())
+        el2, eg2 = abs(l2 - float(lo)) / float(lo), rel_l2(g2.cpu(), go)
+        print(f"  engine {e}: loss err {el2:.2e}, grad err {eg2:.2e}")
+        assert el2 < max(5e-6, 4 * noise_l) and eg2 < max(3e-5, 4 * noise_g)
     # another seed is another mask; p = 0 / eval is the plain network
     eng.dropout_seed = seed + 1
     assert (eng.forward(flat, Xd) - Y).abs().max() > 1e-3
@@ -326,7 +341,7 @@ def test_dropout_module_semantics_and_training_run():
     assert (y1 - y2).abs().max() > 1e-3                                  # two forward passes, two masks
     mean_train = torch.stack([m(x) for _ in range(64)]).mean(0)
     assert (mean_train - y0).abs().mean() < 0.1 * y0.abs().mean() + 0.05  # inverted dropout: roughly unbiased
-    with pytest.raises(PinnError, match="generic engine"):
+    with pytest.raises(PinnError, match="generic engine"):      # forward-only calls with dropout: generic engine only
         Engine(NetDesc(3, 4, 2, 64, (0, 1, 2), engine=2, dropout_p=0.25)).forward(m.flat_params(), x)
     cfg = ns_config(30)
     cfg["layers"]["dropout_rate"] = 0.1
