@@ -260,7 +260,15 @@ constexpr int BATCH_ATOMIC_COPIES = 16;
 
 // RKS / CKS: k-steps that carry real units on the block's rows / columns (k-step-major order: row 4q + r of tile MT is
 // k-step 4 MT + r, column p of tile NT is k-step 4 NT + (p & 3)).  The atomic sink adds only those: 1.6 KB instead of
-// 4 KB per layer at width 20 (the rest of the padded block is exact zeros).
+// 4 KB per layer at width 20 (the rest of the padded block is exact zeros).  Experiments of round 3 around this flush,
+// all measured and dropped: (1) all lanes adding, zeros included — the instruction count becomes a compile-time constant,
+// so the compiler's later waits stay counted instead of vmcnt(0) behind the exec-masked branches — costs more than it
+// gains, the atomic units are the scarcer resource (2^20 points of 100x20 14.9 -> 15.9 ms, 12 514 points 375 -> 455 us);
+// (2) at 12 514 points, a tile's weight gradient handed to a helper wave on the same SIMD through two LDS pad buffers
+// (4 main + 4 helper waves per workgroup): 378 us against 375 — the SIMD's matrix pipe is shared and the chain is
+// bound by its vector-memory waits, not by the 48 MFMAs taken off it; (3) buffer atomics with out-of-range offsets for
+// the masked lanes (static count AND no extra bytes): 365 us at 12 514 points, but the 512-register instances aborted
+// on the GPU box — not pursued on a shared machine.
 template <int MT_N, int NT_N, int NACC, int SINK, int RKS = 4 * MT_N, int CKS = 4 * NT_N>
 __device__ __forceinline__ void bwgrad_flush(float* __restrict__ acc, int woff, int boff, const f4 (&dwa)[NACC][MT_N][NT_N],
                                              float (&bs)[MT_N], int lane) {
