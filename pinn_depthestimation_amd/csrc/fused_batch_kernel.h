@@ -30,9 +30,6 @@
 
 namespace pinn {
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef float f3 __attribute__((ext_vector_type(3)));
-
 __host__ __device__ constexpr int perm16(int c) { return 4 * (c & 3) + (c >> 2); }   // an involution on 0..15
 
 // compile-time loop over the tiles of a batch: the tile index must be a constant at IR generation so that the T jets
@@ -133,17 +130,6 @@ __device__ __forceinline__ void badjoint(const f4 (&G)[K1][NTH], const float (&A
       for (int c = 0; c < K1; ++c) Z[c][s] = G[c][s >> 2][s & 3] * sd;
     }
   }
-}
-
-// jet registers <-> acc-layout tiles (register renames; dead k-steps are exact zeros: zero-padded weights and bias)
-template <int KS, int NTH, int K1>
-__device__ __forceinline__ void btiles(const float (&a)[K1][KS], f4 (&t)[K1][NTH]) {
-#pragma unroll
-  for (int c = 0; c < K1; ++c)
-#pragma unroll
-    for (int kt = 0; kt < NTH; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) t[c][kt][r] = (4 * kt + r < KS) ? a[c][4 * kt + r] : 0.f;
 }
 
 // Compact spill slot of one (tile, layer): quantity c, k-steps [4kt, 4kt+4) at float offset (c*KS + 4kt)*64;
