@@ -116,3 +116,71 @@ def test_trainer_with_an_initialised_nccl_group(tmp_path):
     assert len(a) == len(b) == 20
     assert max(abs(x - y) / abs(x) for x, y in zip(a, b)) < 2e-5
     assert abs(r["plain"]["pred_h"] - r["rccl"]["pred_h"]) <= 1e-4 * abs(r["plain"]["pred_h"])
+
+
+_TWO_RANK = """
+import json, os, sys
+import numpy as np, torch
+import torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from pinn_depthestimation_amd.parallel import Reducer
+from pinn_depthestimation_amd.trainer import PINN
+torch.cuda.set_device(0)
+world = int(os.environ["WORLD_SIZE"])
+if world > 1:
+    dist.init_process_group("gloo")          # both ranks drive cuda:0; gloo stages the device buffers through the host
+cfg = {"layers": {"input_features": 3, "hidden_layers": 8, "hidden_width": 64, "output_features": 4},
+       "adam_optimizer": {"max_it": 12, "learning_rate": 1e-3, "scheduler_step_size": 10, "scheduler_gamma": 0.8},
+       "lbfgs_optimizer": {"max_it": 6, "learning_rate": 1, "max_evaluation": None, "history_size": 100,
+                           "tolerance_grad": 1e-9, "tolerance_change": 1e-12, "line_search_fn": "strong_wolfe"},
+       "loss": {"weight_fid_loss": 1, "weight_res_loss": 1},
+       "data_fidelity": {"inputs": ["t", "x", "y"], "outputs": []},
+       "data_residual": {"inputs": {k: {"requires_grad": ["true"]} for k in "txy"}, "outputs": ["h", "z", "u", "v"]}}
+X = (torch.rand(5001, 3, generator=torch.Generator().manual_seed(3)) * 2 - 1).numpy()     # odd: ragged shards
+torch.manual_seed(1234 + int(os.environ["RANK"]))        # rank 1 starts from DIFFERENT weights: the broadcast from rank 0 must fix that
+tr = PINN(None, None, X, cfg, reducer=Reducer(), log_every=1, checkpoint_every=0)
+assert tr.reducer.active == (world > 1) and tr.reducer.world == world
+tr.train()
+theta = tr.theta.detach().double().cpu().numpy()
+out = {"losses": [h[3] for h in tr.history], "theta_sum": float(theta.sum()), "theta_abs": float(np.abs(theta).sum()),
+       "folded": tr._folded_iters}
+if world > 1:
+    both = [None, None]
+    dist.all_gather_object(both, (out["theta_sum"], out["theta_abs"]))
+    out["ranks_agree"] = both[0] == both[1]
+    dist.destroy_process_group()
+print(json.dumps(out))
+"""
+
+
+def test_two_ranks_on_one_gpu_equal_the_single_process_run():
+    """World size 2 with the HIP evaluator on device tensors: two processes share the box's one GPU (RCCL refuses two
+    ranks on one device, so the collectives go through gloo — the Reducer is backend-agnostic), each runs the fused
+    kernel on its ragged shard, [grad | loss sums] is all-reduced per evaluation.  Adam + L-BFGS losses equal the
+    single-process run on the whole set, and both ranks end on bit-identical parameters although they were
+    initialised differently."""
+    code = _TWO_RANK % {"root": ROOT}
+    port = str(_port())
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=_env(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_PORT=port),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs: q.kill()
+            raise
+        assert p.returncode == 0, e[-3000:]
+        outs.append(json.loads([l for l in o.splitlines() if l.startswith("{")][-1]))
+    one = subprocess.run([sys.executable, "-c", code], env=_env(), capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    ref = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert outs[0]["ranks_agree"] and outs[1]["ranks_agree"]
+    assert outs[0]["theta_sum"] == outs[1]["theta_sum"] and outs[0]["losses"] == outs[1]["losses"]
+    assert outs[0]["folded"] == 0 and ref["folded"] == 12
+    a, b = ref["losses"], outs[0]["losses"]
+    assert len(a) == len(b) >= 13                       # 12 Adam iterations + the L-BFGS evaluations
+    # Adam stage: the shard sums add up to the whole-set sums (fp32 association only)
+    assert max(abs(x - y) / abs(x) for x, y in zip(a[:12], b[:12])) < 5e-5, (a[:12], b[:12])
+    # L-BFGS amplifies last-bit differences in its line search: same descent, not the same digits
+    assert abs(a[-1] - b[-1]) < 0.05 * abs(a[-1]), (a[-1], b[-1])
