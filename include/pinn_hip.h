@@ -120,8 +120,11 @@ typedef struct pinn_desc {
 
 typedef struct pinn_residual_spec {
   int32_t residual_id;
-  int32_t out_col[PINN_MAX_ROLES]; /* output column of each role, in the role order above */
-  int32_t dir_of[PINN_MAX_DIRS];   /* index into desc.dir_col of each direction role */
+  int32_t out_col[PINN_MAX_ROLES]; /* output column of each role, in the role order above; the network may have MORE
+                                      output columns than roles, in any order (entries beyond the residual's roles
+                                      are ignored, whatever they hold) */
+  int32_t dir_of[PINN_MAX_DIRS];   /* index into desc.dir_col of each direction role (entries beyond the residual's
+                                      directions are ignored) */
   int32_t flags;                   /* bit0: 1 = "corrected" radiation stress (unused; E==0 bug-compatible, physics.py:106) */
   float param[4];                  /* continuity_only: param[0]=threshold (25.5), param[1]=anchor (0.75) */
 } pinn_residual_spec;

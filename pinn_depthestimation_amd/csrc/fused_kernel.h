@@ -584,6 +584,8 @@ __device__ __forceinline__ void residual_tile(const FusedParams& P, const f4 (&o
   if constexpr (GRAD) scatter_adjoint<K1, 1 + ND, NR>(tb, g, sm, G, valid, p, q);
 }
 
+// P.out_col entries of roles the residual does not use must be -1 (pinn_abi.hip check_spec normalises every spec):
+// the search below covers all PINN_MAX_ROLES entries, and a stale 0 would claim output column 0.
 template <int K1>
 __device__ __forceinline__ void build_scatter_maps(const FusedParams& P, int q, ScatterMap<K1>& sm, ScatterMap<K1>& sm_mse) {
 #pragma unroll

@@ -141,7 +141,12 @@ static int residual_terms(int id) {
   return -1;
 }
 
-static int check_spec(const Net& n, const pinn_residual_spec* sp) {
+// Checks the roles the residual USES (its first nr output roles, nd direction roles) and returns in *norm a copy whose
+// unused entries are inert: out_col = -1 (matches no output column), dir_of = -1 (quantity 0 is never a direction).
+// The engines' per-lane scatter tables are built by searching ALL PINN_MAX_ROLES entries for "which role lives in
+// this column"; an unused entry left at 0 (zero-initialised structs: every caller) claimed output column 0 whenever no
+// real role sat there, and the output adjoint of that column was read from beyond the roles' rows.
+static int check_spec(const Net& n, const pinn_residual_spec* sp, pinn_residual_spec* norm) {
   if (!sp) { set_error("spec is NULL"); return PINN_ERR_INVALID; }
   int nr = 0, nd = 0;
   switch (sp->residual_id) {
@@ -161,6 +166,9 @@ static int check_spec(const Net& n, const pinn_residual_spec* sp) {
       set_error("dir_of[%d]=%d but the network carries %d tangent directions", d, sp->dir_of[d], n.k);
       return PINN_ERR_INVALID;
     }
+  *norm = *sp;
+  for (int r = nr; r < PINN_MAX_ROLES; ++r) norm->out_col[r] = -1;
+  for (int d = nd; d < PINN_MAX_DIRS; ++d) norm->dir_of[d] = -1;
   return PINN_OK;
 }
 
@@ -260,12 +268,12 @@ static int32_t residual_impl(const pinn_desc* desc, const pinn_residual_spec* sp
                              const float* params, const float* X, int64_t N, float* term_sums, float* grad_flat,
                              void* ws, int64_t ws_bytes, void* stream, bool want_grad) {
   Net n; int rc = make_net(desc, &n); if (rc) return rc;
-  rc = check_spec(n, spec); if (rc) return rc;
+  pinn_residual_spec nspec; rc = check_spec(n, spec, &nspec); if (rc) return rc;
   if (!params || (!X && N > 0) || N < 0 || !term_sums || (want_grad && (!grad_flat || !term_scale))) {
     set_error("NULL pointer argument"); return PINN_ERR_INVALID;
   }
   LossReq rq; memset(&rq, 0, sizeof(rq));
-  rq.kind = 0; rq.n_split = -1; rq.spec = *spec; rq.scale = term_scale; rq.sums = term_sums;
+  rq.kind = 0; rq.n_split = -1; rq.spec = nspec; rq.scale = term_scale; rq.sums = term_sums;
   rq.grad = want_grad ? grad_flat : nullptr; rq.n_terms = residual_terms(spec->residual_id);
   if (N == 0) { (void)hipMemsetAsync(term_sums, 0, rq.n_terms * sizeof(float), (hipStream_t)stream); return PINN_OK; }
   const int e = pick_engine(desc, n, want_grad, &rc); if (rc) return rc;
@@ -312,7 +320,7 @@ static int32_t residual_mse_impl(int64_t n_split, const pinn_desc* desc, const p
                                     const float* params, const float* X, int64_t N, float* term_sums,
                                     float* col_sums, float* grad_flat, void* ws, int64_t ws_bytes, void* stream) {
   Net n; int rc = make_net(desc, &n); if (rc) return rc;
-  rc = check_spec(n, spec); if (rc) return rc;
+  pinn_residual_spec nspec; rc = check_spec(n, spec, &nspec); if (rc) return rc;
   if (n_split > N) { set_error("n_res=%lld exceeds N=%lld", (long long)n_split, (long long)N); return PINN_ERR_INVALID; }
   if (!params || ((!X || (!T && n_split != N)) && N > 0) || N < 0 || !term_sums || !col_sums || !out_col || !grad_flat || !term_scale ||
       !col_scale) {
@@ -320,7 +328,7 @@ static int32_t residual_mse_impl(int64_t n_split, const pinn_desc* desc, const p
   }
   if (n_cols < 1 || n_cols > PINN_MAX_ROLES) { set_error("n_cols=%d outside 1..%d", n_cols, PINN_MAX_ROLES); return PINN_ERR_INVALID; }
   LossReq rq; memset(&rq, 0, sizeof(rq));
-  rq.kind = 2; rq.n_split = n_split; rq.spec = *spec; rq.scale = term_scale; rq.sums = term_sums; rq.n_terms = residual_terms(spec->residual_id);
+  rq.kind = 2; rq.n_split = n_split; rq.spec = nspec; rq.scale = term_scale; rq.sums = term_sums; rq.n_terms = residual_terms(spec->residual_id);
   rq.T = T; rq.n_cols = n_cols; rq.mse_scale = col_scale; rq.mse_sums = col_sums; rq.grad = grad_flat;
   for (int j = 0; j < n_cols; ++j) {
     if (out_col[j] < 0 || out_col[j] >= n.d_out) { set_error("out_col[%d]=%d out of range", j, out_col[j]); return PINN_ERR_INVALID; }
@@ -378,7 +386,7 @@ int32_t pinn_loss_grad_adam_step(const pinn_desc* desc, const pinn_residual_spec
                                  int64_t ws_bytes, void* stream) {
   Net n; int rc = make_net(desc, &n); if (rc) return rc;
   if (!spec || !adam) { set_error("NULL pointer argument"); return PINN_ERR_INVALID; }
-  rc = check_spec(n, spec); if (rc) return rc;
+  pinn_residual_spec nspec; rc = check_spec(n, spec, &nspec); if (rc) return rc;
   if (!params || !X || N < 1 || !term_sums || !term_scale || !grad_flat || !adam->m || !adam->v || adam->step < 1) {
     set_error("bad arguments"); return PINN_ERR_INVALID;
   }
@@ -387,7 +395,7 @@ int32_t pinn_loss_grad_adam_step(const pinn_desc* desc, const pinn_residual_spec
   if (n_cols == 0 && n_res != N) { set_error("no fidelity columns: n_res must equal N"); return PINN_ERR_INVALID; }
   if (n_cols > 0 && (!out_col || !col_scale || !col_sums || (!T && n_res != N))) { set_error("NULL pointer argument"); return PINN_ERR_INVALID; }
   LossReq rq; memset(&rq, 0, sizeof(rq));
-  rq.spec = *spec; rq.scale = term_scale; rq.sums = term_sums; rq.n_terms = residual_terms(spec->residual_id);
+  rq.spec = nspec; rq.scale = term_scale; rq.sums = term_sums; rq.n_terms = residual_terms(spec->residual_id);
   rq.T = T; rq.n_cols = n_cols; rq.mse_scale = col_scale; rq.mse_sums = col_sums; rq.grad = grad_flat;
   for (int j = 0; j < n_cols; ++j) {
     if (out_col[j] < 0 || out_col[j] >= n.d_out) { set_error("out_col[%d]=%d out of range", j, out_col[j]); return PINN_ERR_INVALID; }

@@ -37,6 +37,10 @@ CASES = {
     "pe_2x16": (2, 6, 2, 16, (0, 1), "physics_equation", ("x", "y"), ("h", "U", "V", "eta_mean", "Hrms", "k")),
     "cf_3x32": (2, 3, 3, 32, (0, 1), "continuity_ftemp", ("x", "y"), ("U", "V", "h")),
     "pe_1x10": (2, 6, 1, 10, (0, 1), "physics_equation", ("x", "y"), ("h", "U", "V", "eta_mean", "Hrms", "k")),
+    # output column 0 is NOT one of the residual's roles, roles spill into the second group of four output columns
+    # (round-3 regression: unused spec entries claimed column 0; found by test_sweep_gpu.py)
+    "ns_out_first_3x12": (3, 7, 3, 12, (0, 1, 2), "Navier_Stokes", ("t", "x", "y"), ("aux0", "aux1", "h", "z", "u", "v", "aux2")),
+    "cf_out_first_2x64": (2, 5, 2, 64, (0, 1), "continuity_ftemp", ("x", "y"), ("aux0", "aux1", "h", "U", "V")),
 }
 
 

@@ -1,0 +1,119 @@
+"""Seeded random sweep over what the fused engine accepts — network shape (depth 1..40, width 3..64, extra input / output
+columns, shuffled column order, an extra differentiated input), residual, request kind (residual / one pass with fidelity
+columns / split point set) and point count (1 .. 150 001: one tile, ragged tails, the cooperative range, one-tile
+batches, full batches) — every fused kernel that takes the case (AUTO's pick, tile, cooperative, batch) against the
+GENERIC engine (one thread per point, no MFMA, no shared code beyond residuals.h; itself pinned by the oracle in
+test_engine_gpu.py) on the same device buffers.  fp32 both sides: sums 1e-4 (summation order), gradient 1e-4 rel-L2 — the
+generic kernels' own fp32 accumulation is the noisier side (continuity_only, 20 000 points: generic 2.2e-5 from the fp64
+oracle, the fused kernels 7e-8; tools/sweep_debug.py) and a wrong kernel is off by >= 1e-2.
+
+Found by this sweep (round 3): a residual spec's UNUSED role entries (zero-filled) claimed output column 0 in the
+engines' scatter tables whenever no real role sat in column 0 — garbage output adjoints for networks whose first
+output column is not one of the residual's roles.  pinn_abi.hip now hands the engines a normalised spec."""
+import random
+
+import pytest
+import torch
+
+from pinn_depthestimation_amd import Engine, NetDesc, ResidualSpec
+from pinn_depthestimation_amd._lib import (ENGINE_AUTO, ENGINE_FUSED_BATCH, ENGINE_FUSED_COOP, ENGINE_FUSED_TILE,
+                                           ENGINE_GENERIC, ENGINE_WIDE)
+from pinn_depthestimation_amd.dnn import init_flat_params
+from pinn_depthestimation_amd.engine import RESIDUAL_ROLES, PinnError
+
+pytestmark = pytest.mark.gpu
+
+WIDTHS = [3, 7, 10, 12, 16, 17, 20, 24, 28, 32, 33, 40, 48, 57, 64]
+POINTS = [1, 15, 37, 243, 700, 4097, 9600, 20000, 70001, 150001]
+KERNELS = {"auto": ENGINE_AUTO, "tile": ENGINE_FUSED_TILE, "coop": ENGINE_FUSED_COOP, "batch": ENGINE_FUSED_BATCH}
+
+
+WIDE_WIDTHS = [65, 72, 100, 128, 129, 200, 256]
+WIDE_KERNELS = {"auto": ENGINE_AUTO, "wide": ENGINE_WIDE}
+
+
+def draw(seed, wide=False):
+    r = random.Random(seed)
+    res = r.choice(sorted(RESIDUAL_ROLES))
+    _, out_roles, dir_roles = RESIDUAL_ROLES[res]
+    inn = list(dir_roles) + [f"in{i}" for i in range(r.choice([0, 0, 1, 2]))]
+    outn = list(out_roles) + [f"out{i}" for i in range(r.choice([0, 0, 1, 3]))]
+    r.shuffle(inn); r.shuffle(outn)
+    gc = sorted(inn.index(d) for d in dir_roles)
+    extra = [i for i in range(len(inn)) if i not in gc]
+    if extra and len(gc) < 3 and r.random() < 0.4:
+        gc = sorted(gc + [r.choice(extra)])          # a differentiated input no residual role uses (k grows by one)
+    L = r.choice([1, 2, 3, 4, 6, 8, 10, 12, 14, 40]) if seed % 7 else r.choice([1, 2, 3])
+    W = r.choice(WIDTHS)
+    N = r.choice(POINTS)
+    if L == 40: W, N = min(W, 24), min(N, 20000)
+    if wide:
+        L, W, N = r.choice([1, 2, 3, 5, 12]), r.choice(WIDE_WIDTHS), r.choice(POINTS[:7])
+    kind = r.choice(["residual", "residual", "onepass", "split"])
+    return res, inn, outn, tuple(gc), L, W, N, kind
+
+
+@pytest.mark.parametrize("seed", range(56))
+def test_random_case_against_the_generic_engine(seed):
+    check(seed, draw(seed), KERNELS)
+
+
+@pytest.mark.parametrize("seed", range(1000, 1024))
+def test_random_wide_case_against_the_generic_engine(seed):
+    """The same sweep over 64 < width <= 256 (fp32 mode): the wide engine's three kernels per layer."""
+    check(seed, draw(seed, wide=True), WIDE_KERNELS)
+
+
+def check(seed, case, kernels):
+    res, inn, outn, gc, L, W, N, kind = case
+    d_in, d_out = len(inn), len(outn)
+    g = torch.Generator().manual_seed(100 + seed)
+    X = (torch.rand(N, d_in, generator=g) * 2 - 1).cuda()
+    if res == "continuity_only":
+        X[:, inn.index("x")] *= 40                   # x < 25.5 selects a real subset
+    base = NetDesc(d_in, d_out, L, W, gc)
+    params = init_flat_params(base.layers, "xavier", g).cuda()
+    nP = base.n_params
+    params[nP - d_out:] = torch.rand(d_out, generator=g).cuda() * 0.2
+    if res == "physics_equation":
+        params[nP - d_out + outn.index("h")] = 0.75
+        params[nP - d_out + outn.index("k")] = 0.5
+    n_fid = {"residual": 0, "onepass": N, "split": max(1, N // 5)}[kind]
+    fid_cols = sorted(random.Random(seed).sample(range(d_out), min(d_out, 1 + seed % 3)))
+    T = torch.rand(n_fid, len(fid_cols), generator=g).cuda()
+    n_res = N - n_fid if kind == "split" else N
+    if kind == "split" and n_res == 0:
+        kind, n_res, n_fid = "residual", N, 0
+    desc_of = lambda e: NetDesc(d_in, d_out, L, W, gc, engine=e)
+    spec = ResidualSpec.from_names(res, inn, gc, outn)
+    scale = torch.full((spec.n_terms,), 1.0 / max(n_res, 1), device="cuda") * torch.tensor([1.0, 0.5, 2.0, 1.5][:spec.n_terms], device="cuda")
+    cscale = torch.full((len(fid_cols),), 0.7 / max(n_fid, 1), device="cuda")
+
+    def run(e):
+        eng, grad = Engine(desc_of(e)), torch.zeros(nP, device="cuda")
+        if kind == "residual":
+            s, c = eng.residual_loss_grad(spec, scale, params, X, grad), torch.zeros(0, device="cuda")
+        elif kind == "onepass":
+            s, c = eng.residual_mse_loss_grad(spec, scale, T, fid_cols, cscale, params, X, grad)
+        else:
+            s, c = eng.residual_mse_split_loss_grad(spec, scale, T, fid_cols, cscale, params, X, n_res, grad)
+        torch.cuda.synchronize()
+        return torch.cat([s, c]).double().cpu(), grad.double().cpu()
+
+    s0, g0 = run(ENGINE_GENERIC)
+    assert torch.isfinite(s0).all() and torch.isfinite(g0).all() and g0.norm() > 0
+    ran, worst = [], 0.0
+    for tag, e in kernels.items():
+        try:
+            s1, g1 = run(e)
+        except PinnError as err:
+            assert tag != "auto", err                 # AUTO takes everything (falls back to the generic kernels itself)
+            assert "support" in str(err) or "engine" in str(err), err
+            continue
+        ran.append(tag)
+        rel = float((g1 - g0).norm() / g0.norm())
+        worst = max(worst, rel)
+        assert torch.allclose(s1, s0, rtol=1e-4, atol=1e-9), (tag, s1, s0)
+        assert rel < 1e-4, (tag, rel)
+    print(f"seed {seed}: {res} {d_in}->{L}x{W}->{d_out} k={len(gc)} N={N} {kind}: {'/'.join(ran)} (worst gradient rel-L2 {worst:.1e})")
+    assert ("tile" in ran) if W <= 64 else ("wide" in ran)

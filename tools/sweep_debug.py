@@ -1,0 +1,62 @@
+"""Debug helper next to tests/test_sweep_gpu.py: one hand-given case, every fused kernel against the generic engine,
+gradient differences per parameter block.   python tools/sweep_debug.py RESIDUAL D_IN D_OUT L W K N [runs]
+(INN / OUTN / GC in the environment: comma lists overriding the column names and the differentiated columns)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pinn_depthestimation_amd import Engine, NetDesc, ResidualSpec
+from pinn_depthestimation_amd._lib import ENGINE_AUTO, ENGINE_FUSED_BATCH, ENGINE_FUSED_COOP, ENGINE_FUSED_TILE, ENGINE_GENERIC
+from pinn_depthestimation_amd.dnn import init_flat_params
+from pinn_depthestimation_amd.engine import RESIDUAL_ROLES, PinnError
+
+res = sys.argv[1]
+d_in, d_out, L, W, k, N = (int(a) for a in sys.argv[2:8])
+runs = int(sys.argv[8]) if len(sys.argv) > 8 else 1
+_, out_roles, dir_roles = RESIDUAL_ROLES[res]
+inn = list(dir_roles) + [f"in{i}" for i in range(d_in - len(dir_roles))]
+outn = list(out_roles) + [f"out{i}" for i in range(d_out - len(out_roles))]
+gc = tuple(range(k))
+if os.environ.get("INN"): inn = os.environ["INN"].split(",")
+if os.environ.get("OUTN"): outn = os.environ["OUTN"].split(",")
+if os.environ.get("GC"): gc = tuple(int(c) for c in os.environ["GC"].split(","))
+g = torch.Generator().manual_seed(7)
+X = (torch.rand(N, d_in, generator=g) * 2 - 1).cuda()
+if res == "continuity_only": X[:, inn.index("x")] *= 40
+base = NetDesc(d_in, d_out, L, W, gc)
+params = init_flat_params(base.layers, "xavier", g).cuda()
+nP = base.n_params
+params[nP - d_out:] = torch.rand(d_out, generator=g).cuda() * 0.2 + 0.3
+spec = ResidualSpec.from_names(res, inn, gc, outn)
+scale = torch.full((spec.n_terms,), 1.0 / N, device="cuda")
+if res == "continuity_only":          # the reference's means (physics.py:24-28): over all points / over the points with x < 25.5
+    scale = torch.tensor([1.0 / N, 1.0 / float((X[:, inn.index("x")] < 25.5).sum()), 0.0], device="cuda")
+print(res, inn, outn, gc, "L", L, "W", W, "N", N)
+def run(e):
+    eng, grad = Engine(NetDesc(d_in, d_out, L, W, gc, engine=e)), torch.zeros(nP, device="cuda")
+    s = eng.residual_loss_grad(spec, scale, params, X, grad)
+    torch.cuda.synchronize()
+    return s.double().cpu(), grad.double().cpu()
+s0, g0 = run(ENGINE_GENERIC)
+if os.environ.get("ORACLE"):          # fp64 CPU oracle (checker only) as the comparator instead of the generic engine
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from golden_util import oracle_loss_and_grad
+    from oracle import pinn_oracle as O
+    pl = O.unflatten(params.cpu(), base.layers)
+    _, go = oracle_loss_and_grad(pl, X.cpu(), res, inn, outn, gc, torch.float64)
+    go = go.double()
+    print(f"generic vs fp64 oracle: grad rel {float((g0 - go).norm() / go.norm()):.2e}")
+    g0 = go
+offs, o = [], 0
+for l, (a, b) in enumerate(zip(base.layers[:-1], base.layers[1:])):
+    offs.append((f"W{l}", o, o + a * b)); o += a * b
+    offs.append((f"b{l}", o, o + b)); o += b
+for tag, e in {"auto": ENGINE_AUTO, "tile": ENGINE_FUSED_TILE, "coop": ENGINE_FUSED_COOP, "batch": ENGINE_FUSED_BATCH}.items():
+    for it in range(runs):
+        try:
+            s1, g1 = run(e)
+        except PinnError as err:
+            print(tag, "refused"); break
+        rel = float((g1 - g0).norm() / g0.norm())
+        print(f"{tag}: sums rel {float(((s1 - s0) / s0).abs().max()):.1e} grad rel {rel:.2e}")
+        if rel > 1e-4:
+            print("   per block:", " ".join(f"{n}:{float((g1[a:b] - g0[a:b]).norm() / g0[a:b].norm().clamp_min(1e-30)):.0e}" for n, a, b in offs))
