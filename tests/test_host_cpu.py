@@ -176,15 +176,21 @@ def test_forward_refuses_cpu_tensors_in_both_modes():
             m(torch.zeros(3, 2))
 
 
-def test_dropout_refused_on_the_mfma_engines_and_bad_rates_rejected():
-    """pinn_desc.dropout_p > 0 runs on the generic engine: AUTO routes there, explicit FUSED / WIDE are refused at
-    the C-ABI (no GPU needed: pinn_query_workspace validates and picks the engine)."""
+def test_dropout_engine_routing_and_bad_rates_rejected():
+    """pinn_desc.dropout_p > 0: AUTO takes every network (generic kernels, or the fused tile kernel's dropout instance for
+    gradient passes at hidden width 33..64); explicit FUSED / FUSED_TILE are accepted in that width class only, the
+    cooperative / batch kernels and the wide engine are refused at the C-ABI (no GPU needed: pinn_query_workspace
+    validates and picks the engine)."""
     lib = _lib.load()
     need = C.c_int64()
-    ok = NetDesc(3, 4, 8, 64, (0, 1, 2), dropout_p=0.2)
-    assert lib.pinn_query_workspace(C.byref(ok.c_struct()), 1000, C.byref(need)) == 0 and need.value > 0
-    for eng in (2, 3, 4):
-        bad = NetDesc(3, 4, 8, 64 if eng != 3 else 128, (0, 1, 2), engine=eng, dropout_p=0.2)
+    for W in (20, 64, 128):
+        ok = NetDesc(3, 4, 8, W, (0, 1, 2), dropout_p=0.2)
+        assert lib.pinn_query_workspace(C.byref(ok.c_struct()), 1000, C.byref(need)) == 0 and need.value > 0
+    for eng, W in ((2, 64), (4, 64), (2, 48)):
+        fused = NetDesc(3, 4, 8, W, (0, 1, 2), engine=eng, dropout_p=0.2)
+        assert lib.pinn_query_workspace(C.byref(fused.c_struct()), 1000, C.byref(need)) == 0 and need.value > 0
+    for eng, W in ((3, 128), (5, 64), (6, 20), (2, 20), (4, 20)):
+        bad = NetDesc(3, 4, 8, W, (0, 1, 2), engine=eng, dropout_p=0.2)
         assert lib.pinn_query_workspace(C.byref(bad.c_struct()), 1000, C.byref(need)) == -2
         assert b"generic engine" in lib.pinn_last_error()
     for p in (-0.1, 1.0):
