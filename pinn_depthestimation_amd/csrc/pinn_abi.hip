@@ -214,18 +214,31 @@ int32_t pinn_param_count(const pinn_desc* desc, int64_t* count) {
 int32_t pinn_query_workspace(const pinn_desc* desc, int64_t N, int64_t* bytes) {
   Net n; int rc = make_net(desc, &n); if (rc) return rc;
   if (!bytes || N < 0) { set_error("bad arguments"); return PINN_ERR_INVALID; }
-  // one workspace must serve every call on this network: plain (k = 0) forwards, and gradient calls
-  // that AUTO routes to another engine than the forward (k = 1 networks: fused forward, generic gradient)
-  auto ws_of = [&](int e) {
-    return e == PINN_ENGINE_FUSED ? fused_workspace_bytes(n, N)
-         : e == PINN_ENGINE_WIDE ? wide_workspace_bytes(n, N) : generic_workspace_bytes(n, N);
+  // one workspace must serve every call on this network: gradient calls that AUTO routes to another engine than the
+  // forward (k = 1 networks: fused forward, generic gradient), and the calls that run the network WITHOUT its tangents
+  // (pinn_forward, pinn_mse_loss_grad, pinn_jet_backward without gdY: k = 0), which may land on yet another engine
+  // (k = 1 at width 65..256: jets on the generic kernels, plain forwards on the wide engine)
+  auto need = [&](const Net& nn, int* err) -> int64_t {
+    auto ws_of = [&](int e) {
+      return e == PINN_ENGINE_FUSED ? fused_workspace_bytes(nn, N)
+           : e == PINN_ENGINE_WIDE ? wide_workspace_bytes(nn, N) : generic_workspace_bytes(nn, N);
+    };
+    int rc1 = PINN_OK, rc2 = PINN_OK;
+    const int e = pick_engine(desc, nn, false, &rc1);
+    const int eg = pick_engine(desc, nn, true, &rc2);
+    if (rc1 && rc2) { *err = rc1; return -1; }      // neither kind of call is served on the engine asked for
+    int64_t b = rc1 ? -1 : ws_of(e);
+    if (rc2 == PINN_OK && (rc1 || eg != e)) { const int64_t bg = ws_of(eg); if (bg > b) b = bg; }
+    return b;
   };
-  int rc2 = PINN_OK;
-  const int e = pick_engine(desc, n, false, &rc);
-  const int eg = pick_engine(desc, n, true, &rc2);
-  if (rc && rc2) return rc;                       // neither kind of call is served on the engine asked for
-  int64_t b = rc ? -1 : ws_of(e);
-  if (rc2 == PINN_OK && (rc || eg != e)) { const int64_t bg = ws_of(eg); if (bg > b) b = bg; }
+  int64_t b = need(n, &rc);
+  if (b < 0 && rc) return rc;
+  if (n.k > 0) {
+    Net n0 = n; n0.k = 0; n0.K1 = 1;
+    int rc0 = PINN_OK;
+    const int64_t b0 = need(n0, &rc0);               // (refused on the engine asked for: those calls fail by themselves)
+    if (b0 > b) b = b0;
+  }
   if (b < 0) { set_error("network not supported"); return PINN_ERR_UNSUPPORTED; }
   *bytes = b;
   return PINN_OK;

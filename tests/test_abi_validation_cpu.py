@@ -141,3 +141,19 @@ def test_abi_folded_adam_iteration_validation(lib):
     assert lib.pinn_adam_loop(*args, C.byref(st), 2, None, fake, 1 << 30, None) == INVALID
     assert lib.pinn_adam_loop(*args, None, 2, lr, fake, 1 << 30, None) == INVALID
     assert lib.pinn_adam_loop(*args, C.byref(st), 0, lr, fake, 1 << 30, None) == OK            # zero iterations: nothing to do
+
+
+def test_abi_workspace_serves_the_calls_that_drop_the_tangents(lib):
+    """pinn_forward / pinn_mse_loss_grad run a k > 0 network as a k = 0 one, which AUTO may give to ANOTHER engine:
+    k = 1 at width 65..256 has its jets on the generic kernels and its plain forward on the wide engine (round-3
+    defect found by tests/test_sweep_gpu.py: the query sized the generic kernels' workspace only)."""
+    need, plain = C.c_int64(), C.c_int64()
+    for shape in ((2, 4, 2, 72), (1, 6, 12, 72), (1, 5, 5, 100), (3, 4, 4, 32), (3, 4, 8, 64), (3, 4, 12, 256)):
+        d_in, d_out, L, W = shape
+        for k in (1, 2, 3):
+            if k > d_in: continue
+            for N in (15, 700, 9600):
+                jet = NetDesc(d_in, d_out, L, W, tuple(range(k)))
+                assert lib.pinn_query_workspace(C.byref(jet.c_struct()), N, C.byref(need)) == OK, err(lib)
+                assert lib.pinn_query_workspace(C.byref(NetDesc(d_in, d_out, L, W, ()).c_struct()), N, C.byref(plain)) == OK
+                assert need.value >= plain.value, (shape, k, N, need.value, plain.value)

@@ -117,3 +117,141 @@ def check(seed, case, kernels):
         assert rel < 1e-4, (tag, rel)
     print(f"seed {seed}: {res} {d_in}->{L}x{W}->{d_out} k={len(gc)} N={N} {kind}: {'/'.join(ran)} (worst gradient rel-L2 {worst:.1e})")
     assert ("tile" in ran) if W <= 64 else ("wide" in ran)
+
+
+def draw_net(seed):
+    """A random network and point set with no residual attached: any input / output count, 0..3 differentiated inputs."""
+    r = random.Random(seed)
+    d_in, d_out = r.choice([1, 2, 3, 4, 6]), r.choice([1, 2, 3, 4, 5, 6, 9])
+    k = r.choice([0, 0, 1, 2, 3, 3])
+    gc = tuple(sorted(r.sample(range(d_in), min(k, d_in))))
+    W = r.choice(WIDTHS + WIDE_WIDTHS[:5] if seed % 3 else WIDTHS)
+    L = r.choice([1, 2, 3, 5, 8, 12])
+    N = r.choice(POINTS[:8])
+    return d_in, d_out, gc, L, W, N
+
+
+ALL_KERNELS = dict(KERNELS, wide=ENGINE_WIDE)
+
+
+@pytest.mark.parametrize("seed", range(2000, 2048))
+def test_random_forward_and_jet_against_the_generic_engine(seed):
+    """pinn_forward / pinn_forward_jet (DNN.forward and the compute_gradient columns, dnn.py:54-55, physics.py:6-15): Y
+    and dY of every engine that takes the network against the generic kernels, 5e-6 of the largest entry."""
+    d_in, d_out, gc, L, W, N = draw_net(seed)
+    g = torch.Generator().manual_seed(seed)
+    X = (torch.rand(N, d_in, generator=g) * 2 - 1).cuda()
+    base = NetDesc(d_in, d_out, L, W, gc)
+    params = init_flat_params(base.layers, "xavier", g).cuda()
+    ref = Engine(base.with_(engine=ENGINE_GENERIC))
+    Y0 = ref.forward(params, X)
+    Yj0, dY0 = ref.forward_jet(params, X) if gc else (Y0, None)
+    assert torch.isfinite(Y0).all() and torch.equal(Y0, Yj0)
+    ran = []
+    for tag, e in ALL_KERNELS.items():
+        eng = Engine(base.with_(engine=e))
+        try:
+            Y1 = eng.forward(params, X)
+            Yj1, dY1 = eng.forward_jet(params, X) if gc else (Y1, None)
+        except PinnError as err:
+            assert tag != "auto", err
+            continue
+        torch.cuda.synchronize()
+        ran.append(tag)
+        tol = 5e-6 * max(1.0, float(Y0.abs().max()))
+        assert float((Y1 - Y0).abs().max()) < tol and float((Yj1 - Y0).abs().max()) < tol, tag
+        if gc:
+            assert float((dY1 - dY0).abs().max()) < 5e-6 * max(1.0, float(dY0.abs().max())), tag
+    print(f"seed {seed}: {d_in}->{L}x{W}->{d_out} k={len(gc)} N={N}: {'/'.join(ran)}")
+    assert len(ran) >= 1
+
+
+@pytest.mark.parametrize("seed", range(3000, 3032))
+def test_random_fidelity_only_request_against_the_generic_engine(seed):
+    """pinn_mse_loss_grad (train.py:136-141: the fidelity term alone, k = 0 networks included)."""
+    d_in, d_out, gc, L, W, N = draw_net(seed)
+    g = torch.Generator().manual_seed(seed)
+    X = (torch.rand(N, d_in, generator=g) * 2 - 1).cuda()
+    base = NetDesc(d_in, d_out, L, W, gc)
+    params = init_flat_params(base.layers, "xavier", g).cuda()
+    cols = sorted(random.Random(seed).sample(range(d_out), random.Random(seed + 1).randint(1, min(d_out, 6))))
+    T = torch.rand(N, len(cols), generator=g).cuda()
+    cscale = (torch.rand(len(cols), generator=g) + 0.5).cuda() / N
+    out = {}
+    for tag, e in dict(ALL_KERNELS, generic=ENGINE_GENERIC).items():
+        grad = torch.zeros(base.n_params, device="cuda")
+        try:
+            s = Engine(base.with_(engine=e)).mse_loss_grad(params, X, T, cols, cscale, grad)
+        except PinnError as err:
+            assert tag not in ("auto", "generic"), err
+            continue
+        torch.cuda.synchronize()
+        out[tag] = (s.double().cpu(), grad.double().cpu())
+    s0, g0 = out.pop("generic")
+    assert g0.norm() > 0
+    for tag, (s1, g1) in out.items():
+        assert torch.allclose(s1, s0, rtol=1e-4), (tag, s1, s0)
+        assert float((g1 - g0).norm() / g0.norm()) < 1e-4, tag
+    print(f"seed {seed}: {d_in}->{L}x{W}->{d_out} k={len(gc)} N={N} cols {cols}: {'/'.join(out)}")
+
+
+@pytest.mark.parametrize("seed", range(4000, 4024))
+def test_random_folded_adam_iterations_against_the_separate_calls(seed):
+    """pinn_loss_grad_adam_step on random fused-engine cases (AUTO's kernel pick: cooperative / tile / batch, every
+    packing): four folded iterations against loss call + pinn_adam_step, with a torch write in between."""
+    res, inn, outn, gc, L, W, N, kind = draw(seed)
+    N = max(N, 16)
+    d_in, d_out = len(inn), len(outn)
+    g = torch.Generator().manual_seed(seed)
+    X = (torch.rand(N, d_in, generator=g) * 2 - 1).cuda()
+    if res == "continuity_only":
+        X[:, inn.index("x")] *= 40
+    desc = NetDesc(d_in, d_out, L, W, gc)
+    flat0 = init_flat_params(desc.layers, "xavier", g).cuda()
+    nP = desc.n_params
+    flat0[nP - d_out:] = torch.rand(d_out, generator=g).cuda() * 0.2
+    if res == "physics_equation":
+        flat0[nP - d_out + outn.index("h")] = 0.75
+        flat0[nP - d_out + outn.index("k")] = 0.5
+    n_fid = {"residual": 0, "onepass": N, "split": max(1, N // 5)}[kind]
+    fid = sorted(random.Random(seed).sample(range(d_out), min(d_out, 1 + seed % 3))) if kind != "residual" else []
+    T = torch.rand(n_fid, len(fid), generator=g).cuda() if fid else None
+    n_res = N - n_fid if kind == "split" else N
+    spec = ResidualSpec.from_names(res, inn, gc, outn)
+    scale = torch.full((spec.n_terms,), 1.0 / n_res, device="cuda")
+    cscale = torch.full((len(fid),), 0.7 / max(n_fid, 1), device="cuda") if fid else None
+    runs = {}
+    for mode in ("classic", "folded"):
+        eng = Engine(desc)
+        th, m, v, grad = flat0.clone(), torch.zeros(nP, device="cuda"), torch.zeros(nP, device="cuda"), torch.zeros(nP, device="cuda")
+        ts, cs = torch.zeros(spec.n_terms, device="cuda"), torch.zeros(max(len(fid), 1), device="cuda")[:len(fid)]
+        g1 = None
+        for step in range(1, 5):
+            if step == 3:
+                th.mul_(1.0 + 1e-3)
+            if mode == "folded":
+                ok = eng.loss_grad_adam_step(spec, scale, th, X, n_res if kind == "split" else -1 if fid else N, grad, m, v, step, 1e-3,
+                                             T=T, out_col=fid, col_scale=cscale, term_sums=ts, col_sums=cs if fid else None)
+                if not ok:
+                    pytest.skip("not a one-pass request of the fused engine")
+            else:
+                grad.zero_()
+                if not fid:
+                    eng.residual_loss_grad(spec, scale, th, X, grad, sums=ts)
+                elif kind == "onepass":
+                    eng.residual_mse_loss_grad(spec, scale, T, fid, cscale, th, X, grad, term_sums=ts, col_sums=cs)
+                else:
+                    eng.residual_mse_split_loss_grad(spec, scale, T, fid, cscale, th, X, n_res, grad, term_sums=ts, col_sums=cs)
+                eng.adam_step(th, grad, m, v, step, 1e-3)
+            if step == 1:
+                g1 = (grad.clone(), ts.clone(), cs.clone())
+        torch.cuda.synchronize()
+        runs[mode] = (th, m, v, g1)
+    a, b = runs["classic"], runs["folded"]
+    assert float((a[3][0] - b[3][0]).norm() / a[3][0].norm()) < 5e-6
+    assert torch.allclose(a[3][1], b[3][1], rtol=1e-5) and torch.allclose(a[3][2], b[3][2], rtol=1e-5)
+    # Adam's first steps move every parameter by ~lr whatever the gradient's size: entries whose gradient is at rounding
+    # level may step the other way, so compare in units of the step (4 iterations x 1e-3)
+    assert float((a[0] - b[0]).abs().max()) < 4.1e-3 and float((a[0] - b[0]).norm() / (a[0] - flat0).norm()) < 2e-2
+    assert bool(torch.isfinite(b[0]).all())
+    print(f"seed {seed}: {res} {d_in}->{L}x{W}->{d_out} k={len(gc)} N={N} {kind}")
