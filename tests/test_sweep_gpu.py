@@ -255,3 +255,89 @@ def test_random_folded_adam_iterations_against_the_separate_calls(seed):
     assert float((a[0] - b[0]).abs().max()) < 4.1e-3 and float((a[0] - b[0]).norm() / (a[0] - flat0).norm()) < 2e-2
     assert bool(torch.isfinite(b[0]).all())
     print(f"seed {seed}: {res} {d_in}->{L}x{W}->{d_out} k={len(gc)} N={N} {kind}")
+
+
+@pytest.mark.parametrize("seed", range(5000, 5024))
+def test_random_bf16_mode_case_against_fp32_mode(seed):
+    """precision = bf16 (the chain engine, configs[3]'s mode) over random wide shapes: every path the shape selects —
+    first layer folded into the forward chain or not (d_in <= 3), the streaming output-layer kernels or the wide
+    engine's (d_out <= 4), k = 2 / 3, ragged tile counts — against fp32 mode on the same buffers.  bf16 mode is a
+    TOLERANCE mode (jets carry 8 significant bits): loss sums 3e-2, gradient 1e-1 rel-L2 here (shallow random nets sit at
+    1e-3..1e-2); what this sweep is after is a path that reads or writes the wrong thing, which is off by O(1) or NaN."""
+    r = random.Random(seed)
+    res, inn, outn, gc, _, _, _, kind = draw(seed)
+    L, W, N = r.choice([2, 3, 5, 8, 12]), r.choice(WIDE_WIDTHS), r.choice([15, 243, 700, 4097, 9600, 20000])
+    d_in, d_out = len(inn), len(outn)
+    g = torch.Generator().manual_seed(seed)
+    X = (torch.rand(N, d_in, generator=g) * 2 - 1).cuda()
+    if res == "continuity_only":
+        X[:, inn.index("x")] *= 40
+    base = NetDesc(d_in, d_out, L, W, gc)
+    params = init_flat_params(base.layers, "xavier", g).cuda()
+    nP = base.n_params
+    params[nP - d_out:] = torch.rand(d_out, generator=g).cuda() * 0.2
+    if res == "physics_equation":
+        params[nP - d_out + outn.index("h")] = 0.75
+        params[nP - d_out + outn.index("k")] = 0.5
+    spec = ResidualSpec.from_names(res, inn, gc, outn)
+    scale = torch.full((spec.n_terms,), 1.0 / N, device="cuda")
+    out = {}
+    for tag, prec in (("fp32", 0), ("bf16", 1)):
+        grad = torch.zeros(nP, device="cuda")
+        eng = Engine(base.with_(precision=prec))
+        s = eng.residual_loss_grad(spec, scale, params, X, grad)
+        Y, dY = eng.forward_jet(params, X)
+        torch.cuda.synchronize()
+        out[tag] = (s.double().cpu(), grad.double().cpu(), Y.double().cpu(), dY.double().cpu())
+    (s0, g0, Y0, dY0), (s1, g1, Y1, dY1) = out["fp32"], out["bf16"]
+    rel = float((g1 - g0).norm() / g0.norm())
+    ey, edy = float((Y1 - Y0).abs().max()), float((dY1 - dY0).abs().max() / dY0.abs().max().clamp_min(1e-30))
+    print(f"seed {seed}: {res} {d_in}->{L}x{W}->{d_out} k={len(gc)} N={N}: sums {float(((s1 - s0) / s0.clamp_min(1e-30)).abs().max()):.1e} "
+          f"gradient {rel:.1e} Y {ey:.1e} dY {edy:.1e}")
+    assert torch.isfinite(g1).all() and torch.isfinite(s1).all()
+    live = s0.abs() > 1e-12
+    assert torch.allclose(s1[live], s0[live], rtol=3e-2), (s1, s0)
+    assert rel < 1e-1
+    assert ey < 2e-2 * max(1.0, float(Y0.abs().max())) and edy < 5e-2
+
+
+@pytest.mark.parametrize("seed", range(6000, 6016))
+def test_random_dropout_case_fused_instance_against_the_generic_engine(seed):
+    """nn.Dropout(p > 0) in training mode (dnn.py:38) on the fused tile kernel's dropout instance (width 33..64) against
+    the generic kernels under the SAME counter-based mask (same seed): loss sums and gradient."""
+    r = random.Random(seed)
+    res, inn, outn, gc, _, _, _, _ = draw(seed)
+    L, W, N = r.choice([1, 2, 4, 8, 11]), r.choice([33, 40, 48, 57, 64]), r.choice([15, 243, 700, 4097, 20000, 70001])
+    p = r.choice([0.05, 0.1, 0.3, 0.5])
+    d_in, d_out = len(inn), len(outn)
+    g = torch.Generator().manual_seed(seed)
+    X = (torch.rand(N, d_in, generator=g) * 2 - 1).cuda()
+    if res == "continuity_only":
+        X[:, inn.index("x")] *= 40
+    base = NetDesc(d_in, d_out, L, W, gc, dropout_p=p)
+    params = init_flat_params(base.layers, "xavier", g).cuda()
+    nP = base.n_params
+    params[nP - d_out:] = torch.rand(d_out, generator=g).cuda() * 0.2
+    if res == "physics_equation":
+        params[nP - d_out + outn.index("h")] = 0.75
+        params[nP - d_out + outn.index("k")] = 0.5
+    spec = ResidualSpec.from_names(res, inn, gc, outn)
+    scale = torch.full((spec.n_terms,), 1.0 / N, device="cuda")
+    out = {}
+    for tag, e in (("generic", ENGINE_GENERIC), ("fused", ENGINE_FUSED_TILE), ("auto", ENGINE_AUTO)):
+        eng, grad = Engine(base.with_(engine=e)), torch.zeros(nP, device="cuda")
+        eng.dropout_seed = 1000 + seed
+        try:
+            s = eng.residual_loss_grad(spec, scale, params, X, grad)
+        except PinnError as err:      # the dropout instance keeps the gradient copy in LDS: deeper than ~10 x 64 is refused
+            assert tag == "fused" and "generic engine" in str(err), err
+            continue
+        torch.cuda.synchronize()
+        out[tag] = (s.double().cpu(), grad.double().cpu())
+    s0, g0 = out.pop("generic")
+    for tag, (s1, g1) in out.items():
+        rel = float((g1 - g0).norm() / g0.norm())
+        assert torch.allclose(s1, s0, rtol=1e-4, atol=1e-9), (tag, s1, s0)
+        assert rel < 1e-4, (tag, rel)
+    print(f"seed {seed}: {res} {d_in}->{L}x{W}->{d_out} k={len(gc)} N={N} p={p}: {'/'.join(out)}")
+    assert "auto" in out
