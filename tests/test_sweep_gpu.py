@@ -341,3 +341,35 @@ def test_random_dropout_case_fused_instance_against_the_generic_engine(seed):
         assert rel < 1e-4, (tag, rel)
     print(f"seed {seed}: {res} {d_in}->{L}x{W}->{d_out} k={len(gc)} N={N} p={p}: {'/'.join(out)}")
     assert "auto" in out
+
+
+@pytest.mark.parametrize("seed", range(9000, 9020))
+def test_random_jet_backward_against_the_oracle(seed):
+    """pinn_jet_backward (the VJP behind compute_gradient's generic consumers: grad += d/dtheta [sum(gY*Y) + sum(gdY*dY)])
+    on random networks, tanh and LeakyReLU, any width up to 300, against torch autograd over the oracle's jet (float64)."""
+    from oracle import pinn_oracle as O        # checker only
+    d_in, d_out, gc, L, W, N = draw_net(seed)
+    r = random.Random(seed)
+    if not gc:
+        gc = (r.randrange(d_in),)
+    W = r.choice([W, 300]) if seed % 5 == 0 else W
+    N = min(N, 700)
+    init = r.choice(["xavier", "xavier", "kaiming"])
+    g = torch.Generator().manual_seed(seed)
+    params = O.init_params(O.layer_sizes(d_in, L, W, d_out), init, g)
+    X = torch.rand(N, d_in, generator=g) * 2 - 1
+    gY, gdY = torch.randn(N, d_out, generator=g), torch.randn(len(gc), N, d_out, generator=g)
+    desc = NetDesc(d_in, d_out, L, W, gc, activation=1 if init == "kaiming" else 0)
+    eng = Engine(desc)
+    for with_gdY in (True, False):
+        p64 = [p.double().clone().requires_grad_(True) for p in params]
+        cols = O.split_columns(X.double(), gc)
+        Yo = O.mlp_forward(p64, torch.cat(cols, -1), init)
+        dYo = torch.stack([torch.cat([O.compute_gradient(Yo[:, c:c + 1], cols[j]) for c in range(d_out)], 1) for j in gc])
+        obj = (gY.double() * Yo).sum() + ((gdY.double() * dYo).sum() if with_gdY else 0.0)
+        ref = O.flat_grad(obj, p64)
+        grad = torch.zeros(desc.n_params, device="cuda")
+        eng.jet_backward(O.flatten(params).cuda(), X.cuda(), gY.cuda(), gdY.cuda() if with_gdY else None, grad)
+        rel = float((grad.double().cpu() - ref).norm() / ref.norm())
+        assert rel < 2e-5, (with_gdY, rel)
+    print(f"seed {seed}: {d_in}->{L}x{W}->{d_out} {init} k={len(gc)} N={N}: {rel:.1e}")
