@@ -432,15 +432,17 @@ __global__ __launch_bounds__(P8_THREADS, 2) void k_chain_fwd8(const ChainParams 
   // FOLD: this lane's point of batch tb_ -> its coordinates (three loads whatever d_in: missing columns and points
   // beyond the set read as 0 from an out-of-range offset), then the tile's a_1 from them
   float xr[3] = {0.f, 0.f, 0.f};
-  const __amdgpu_buffer_rsrc_t xrs = jet_rsrc(P.X, (int)(P.n_points * P.d_in * 4 < 0x7fffffff ? P.n_points * P.d_in * 4 : 0x7fffffff));
+  // (the resource covers THIS CHUNK's rows of X: buffer offsets are 32 bits, the whole point set may pass 2 GB)
+  const int64_t x_rest = (P.n_points - P.tile0 * 16) * P.d_in * 4;
+  const __amdgpu_buffer_rsrc_t xrs = jet_rsrc(P.X + P.tile0 * 16 * P.d_in, (int)(x_rest < 0x7fffffff ? (x_rest > 0 ? x_rest : 0) : 0x7fffffff));
   auto load_x = [&](int64_t tb_) {
     int64_t t_ = tb_ * CHAIN_WAVES + (wave >> 1);
     if (t_ >= P.n_tiles) t_ = P.n_tiles - 1;
-    const int64_t pt = (P.tile0 + t_) * 16 + 8 * half + p8;
-    const bool ok = tb_ < n_tb && pt < P.n_points;
+    const int64_t ptl = t_ * 16 + 8 * half + p8;             // row inside this chunk
+    const bool ok = tb_ < n_tb && P.tile0 * 16 + ptl < P.n_points;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const unsigned off = ok && j < P.d_in ? (unsigned)(pt * P.d_in + j) * 4u : 0x7ffffff0u;
+      const unsigned off = ok && j < P.d_in ? (unsigned)(ptl * P.d_in + j) * 4u : 0x7ffffff0u;
       xr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)off, 0, 0));
     }
   };
@@ -954,7 +956,9 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_chain_first_bwd(const Chai
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = lane & 15, q = lane >> 4;
   const unsigned lpos = (4u * p + q) * 16u;
-  const __amdgpu_buffer_rsrc_t xrs = jet_rsrc(P.X, (int)(P.n_points * P.d_in * 4 < 0x7fffffff ? P.n_points * P.d_in * 4 : 0x7fffffff));
+  // (the resource covers THIS CHUNK's rows of X: buffer offsets are 32 bits, the whole point set may pass 2 GB)
+  const int64_t x_rest = (P.n_points - P.tile0 * 16) * P.d_in * 4;
+  const __amdgpu_buffer_rsrc_t xrs = jet_rsrc(P.X + P.tile0 * 16 * P.d_in, (int)(x_rest < 0x7fffffff ? (x_rest > 0 ? x_rest : 0) : 0x7fffffff));
   const int cA = P.dir_col[0], cB = P.dir_col[1], cC = P.dir_col[2];
   for (int64_t t = (int64_t)blockIdx.x * CHAIN_WAVES + wave; t < P.n_tiles; t += (int64_t)gridDim.x * CHAIN_WAVES) {
     const int64_t tbase = uniform64(t) * (K1 * NS * 512);
@@ -963,7 +967,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_chain_first_bwd(const Chai
     float x[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const unsigned off = pt < P.n_points && j < P.d_in ? (unsigned)(pt * P.d_in + j) * 4u : 0x7ffffff0u;
+      const unsigned off = pt < P.n_points && j < P.d_in ? (unsigned)((t * 16 + p) * P.d_in + j) * 4u : 0x7ffffff0u;
       x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)off, 0, 0));
     }
     const bool valid = pt < P.n_points;                        // padding points of the last tile carry no adjoint
