@@ -88,3 +88,40 @@ def test_baseline_size_fused_equals_generic_and_properties():
     s_r, g_r, _ = loss_grad(fused, params, X)
     assert torch.equal(s_r, s_f) or torch.allclose(s_r, s_f, rtol=1e-6)
     assert float((g_r - g_f).norm() / g_f.norm()) < 1e-6
+
+
+@pytest.mark.parametrize("shape", ["ns8x64", "pe10x10", "co100x20"])
+def test_sixteen_million_points_are_sixteen_blocks_and_a_tail(shape):
+    """Maximum sizes (BASELINE configs[3] quotes 16 M points; configs[2] 4 M): 2^24 + 5 points built as sixteen copies of
+    one 2^20-point block plus five more points — sums and gradient must be 16 x the block's + the tail's (same term
+    scales): index arithmetic, persistent tile loops, spill slots and gradient sinks at 1 048 577 tiles; forward rows of
+    the last block equal the first block's."""
+    d_in, d_out, L, W, gc, res, inn, outn = {
+        "ns8x64": (3, 4, 8, 64, (0, 1, 2), "Navier_Stokes", ("t", "x", "y"), ("h", "z", "u", "v")),
+        "pe10x10": (2, 6, 10, 10, (0, 1), "physics_equation", ("x", "y"), ("h", "U", "V", "eta_mean", "Hrms", "k")),
+        "co100x20": (2, 3, 100, 20, (0, 1), "continuity_ftemp", ("x", "y"), ("U", "V", "h"))}[shape]
+    desc = NetDesc(d_in, d_out, L, W, gc)
+    spec = ResidualSpec.from_names(res, inn, gc, outn)
+    g = torch.Generator().manual_seed(11)
+    params = init_flat_params(desc.layers, "xavier", g).cuda()
+    if res == "physics_equation":
+        params[desc.n_params - d_out + 0] = 0.75
+        params[desc.n_params - d_out + 3] = 0.0
+    B = 1 << 20
+    Xb = (torch.rand(B, d_in, generator=g) * 2 - 1).cuda()
+    Xt = (torch.rand(5, d_in, generator=g) * 2 - 1).cuda()
+    big = torch.cat([Xb] * 16 + [Xt]).contiguous()
+    scale = torch.full((spec.n_terms,), 1.0 / big.shape[0], device="cuda")
+    eng = Engine(desc)
+    out = []
+    for X in (Xb, Xt, big):
+        grad = torch.zeros(desc.n_params, device="cuda")
+        s = eng.residual_loss_grad(spec, scale, params, X, grad)
+        out.append((s.double().cpu(), grad.double().cpu()))
+    (sb, gb), (st, gt), (sB, gB) = out
+    assert torch.allclose(sB, 16 * sb + st, rtol=2e-5), (sB, 16 * sb + st)
+    want = 16 * gb + gt
+    assert float((gB - want).norm() / want.norm()) < 2e-5
+    Y = eng.forward(params, big)
+    assert torch.equal(Y[15 * B:16 * B], Y[:B])
+    assert float((Y[16 * B:] - eng.forward(params, Xt)).abs().max()) < 2e-6      # (five points alone: the cooperative kernel's summation order)
