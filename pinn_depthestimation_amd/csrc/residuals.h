@@ -132,8 +132,14 @@ struct ResContinuity {
 // ---- activations (dnn.py:18-21) ------------------------------------------------
 // tanh: odd minimax polynomial below 0.625 (relative error ~1e-7), the
 // exponential form above; abs error <= ~1.5e-7 everywhere in fp32.
+#ifndef PINN_TANH_EXP_ONLY
+#define PINN_TANH_EXP_ONLY 0
+#endif
 __device__ inline float tanh_f32(float x) {
   const float ax = fabsf(x);
+#if PINN_TANH_EXP_ONLY      // experiment: the exponential form everywhere (abs error ~1.5e-7, relative error grows as x -> 0)
+  return copysignf(fmaf(-2.f, __builtin_amdgcn_rcpf(__expf(2.f * ax) + 1.f), 1.f), x);
+#endif
   const float x2 = x * x;
   float p = -5.70498872745e-3f;
   p = fmaf(p, x2, 2.06390887954e-2f);
