@@ -191,13 +191,16 @@ def free_port() -> int:
 def visible_gpu_count() -> int:
     """GPUs this process could open, counted WITHOUT loading HIP (no torch.cuda, no libamdhip64): the launcher must
     stay a process that never touched the GPU.  An explicit *_VISIBLE_DEVICES list wins; otherwise the KFD topology
-    nodes that have SIMDs (CPUs are nodes too) capped by the DRM render nodes this container may actually open."""
+    nodes that have SIMDs (CPUs are nodes too) capped by the DRM render nodes this container may actually open; -1 when
+    sysfs has no KFD topology to read (the launcher then leaves the check to the ranks, which use the real runtime)."""
     import glob
     for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
             return len([x for x in v.split(",") if x.strip() != ""])
     kfd = 0
+    if not os.path.isdir("/sys/class/kfd/kfd/topology/nodes"):
+        return -1              # sysfs is not telling (no KFD topology in this container): the ranks find out for themselves
     for props in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
         try:
             for line in open(props):
@@ -217,7 +220,7 @@ def launch_ranks(args, argv) -> int:
     n = args.gpus
     if not args.test_evaluator:
         have = visible_gpu_count()
-        if have < n:
+        if 0 <= have < n:
             print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible; refusing to run a smaller job under "
                   f"that name", file=sys.stderr, flush=True)
             return 2

@@ -95,6 +95,7 @@ class DNN(nn.Module):
         return ps
 
     def _flatten(self):
+        self.__dict__.pop("_plist", None)      # the slow path re-reads the module tree (a layer replaced since the last time)
         ps = self._ordered_params()
         flat = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in ps])
         off = 0

@@ -379,7 +379,7 @@ class PINN:
     MAX_RUN = 256      # iterations enqueued by one call (pinn_adam_loop)
 
     def _fold_key(self):
-        return (id(self.evaluator), id(self.Xr), id(self.Xf), self.residual_batch)
+        return (id(self.evaluator), id(self.Xr), id(self.Xf), self.residual_batch, self.dnn.training)   # (dropout folds in eval mode only)
 
     def _may_fold(self) -> bool:
         """The folded iteration is worth asking for: switched on, one process, an evaluator that has it, and the engine
