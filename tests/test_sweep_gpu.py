@@ -7,6 +7,11 @@ test_engine_gpu.py) on the same device buffers.  fp32 both sides: sums 1e-4 (sum
 generic kernels' own fp32 accumulation is the noisier side (continuity_only, 20 000 points: generic 2.2e-5 from the fp64
 oracle, the fused kernels 7e-8; tools/sweep_debug.py) and a wrong kernel is off by >= 1e-2.
 
+The committed seed ranges run in seconds; the same draws over 1 200 seeds (ranges widened by hand) pass as well.
+physics_equation cases scale the output layer by 0.25: with eta_mean + h near 0 the residual's 1 / (rho (eta_mean + h))
+term makes two fp32 evaluations differ by 1e-2 (the reference itself: G4's raw-init fixture, 2e-1), which says nothing
+about the kernels.
+
 Found by this sweep (round 3): a residual spec's UNUSED role entries (zero-filled) claimed output column 0 in the
 engines' scatter tables whenever no real role sat in column 0 — garbage output adjoints for networks whose first
 output column is not one of the residual's roles.  pinn_abi.hip now hands the engines a normalised spec."""
@@ -78,6 +83,7 @@ def check(seed, case, kernels):
     if res == "physics_equation":
         params[nP - d_out + outn.index("h")] = 0.75
         params[nP - d_out + outn.index("k")] = 0.5
+        params[nP - d_out - W * d_out:nP - d_out] *= 0.25     # keep eta_mean + h away from 0: 1 / (rho (eta_mean + h)) is singular there
     n_fid = {"residual": 0, "onepass": N, "split": max(1, N // 5)}[kind]
     fid_cols = sorted(random.Random(seed).sample(range(d_out), min(d_out, 1 + seed % 3)))
     T = torch.rand(n_fid, len(fid_cols), generator=g).cuda()
@@ -213,6 +219,7 @@ def test_random_folded_adam_iterations_against_the_separate_calls(seed):
     if res == "physics_equation":
         flat0[nP - d_out + outn.index("h")] = 0.75
         flat0[nP - d_out + outn.index("k")] = 0.5
+        flat0[nP - d_out - W * d_out:nP - d_out] *= 0.25     # keep eta_mean + h away from 0: 1 / (rho (eta_mean + h)) is singular there
     n_fid = {"residual": 0, "onepass": N, "split": max(1, N // 5)}[kind]
     fid = sorted(random.Random(seed).sample(range(d_out), min(d_out, 1 + seed % 3))) if kind != "residual" else []
     T = torch.rand(n_fid, len(fid), generator=g).cuda() if fid else None
@@ -279,6 +286,7 @@ def test_random_bf16_mode_case_against_fp32_mode(seed):
     if res == "physics_equation":
         params[nP - d_out + outn.index("h")] = 0.75
         params[nP - d_out + outn.index("k")] = 0.5
+        params[nP - d_out - W * d_out:nP - d_out] *= 0.25     # keep eta_mean + h away from 0: 1 / (rho (eta_mean + h)) is singular there
     spec = ResidualSpec.from_names(res, inn, gc, outn)
     scale = torch.full((spec.n_terms,), 1.0 / N, device="cuda")
     out = {}
@@ -321,6 +329,7 @@ def test_random_dropout_case_fused_instance_against_the_generic_engine(seed):
     if res == "physics_equation":
         params[nP - d_out + outn.index("h")] = 0.75
         params[nP - d_out + outn.index("k")] = 0.5
+        params[nP - d_out - W * d_out:nP - d_out] *= 0.25     # keep eta_mean + h away from 0: 1 / (rho (eta_mean + h)) is singular there
     spec = ResidualSpec.from_names(res, inn, gc, outn)
     scale = torch.full((spec.n_terms,), 1.0 / N, device="cuda")
     out = {}
