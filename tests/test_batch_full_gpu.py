@@ -47,3 +47,25 @@ def test_full_batch_instances_match_the_tile_kernel(name):
     rel = float((g0 - g1).norm() / g0.norm())
     print(f"{name}: gradient rel-L2 difference tile vs batch {rel:.2e}")
     assert rel < 5e-6
+
+
+@pytest.mark.parametrize("shape", [(3, 4, 8, 64, 0), (2, 6, 3, 48, 0), (5, 9, 1, 33, 0), (3, 4, 5, 64, 1)])
+def test_plain_forward_four_tiles_per_wave_is_bitwise_the_tile_kernel(shape):
+    """pinn_forward above 131 072 points at padded width 64 runs k_fused_plain4 (pinn_fused_plain_w64.hip: four tiles
+    per wave share each weight fetch).  Same fmaf chain per point as the one-tile kernel: Y must be bit-identical
+    (ragged point count: the last pass has one live tile and a half-empty one), and it must agree with the generic kernels."""
+    from pinn_depthestimation_amd._lib import ENGINE_AUTO, ENGINE_GENERIC
+    d_in, d_out, L, W, act = shape
+    N = 150001
+    g = torch.Generator().manual_seed(21)
+    X = (torch.rand(N, d_in, generator=g) * 2 - 1).cuda()
+    desc = NetDesc(d_in, d_out, L, W, (), activation=act)
+    params = init_flat_params(desc.layers, "kaiming" if act else "xavier", g).cuda()
+    Y = {tag: Engine(desc.with_(engine=e)).forward(params, X) for tag, e in
+         (("auto", ENGINE_AUTO), ("tile", ENGINE_FUSED_TILE), ("generic", ENGINE_GENERIC))}
+    torch.cuda.synchronize()
+    assert torch.equal(Y["auto"], Y["tile"])
+    assert float((Y["auto"] - Y["generic"]).abs().max()) < 5e-6 * max(1.0, float(Y["generic"].abs().max()))
+    # a differentiated column in the descriptor does not change what pinn_forward runs (it drops the tangents)
+    jet = NetDesc(d_in, d_out, L, W, (0,), activation=act)
+    assert torch.equal(Engine(jet).forward(params, X), Y["auto"])
