@@ -7,7 +7,8 @@
 namespace pinn {
 
 int launch_fused_drop64(int K1, const FusedParams& P, int grid, size_t lds, hipStream_t s);   // pinn_fused_w64_drop.hip
-int launch_fused_plain64(const FusedParams& P, int grid, hipStream_t s);                          // pinn_fused_plain_w64.hip
+int launch_fused_plain(int WP, const FusedParams& P, int cus, hipStream_t s);                      // pinn_fused_plain_w64.hip
+int64_t fused_plain_min_tiles(int WP, int cus);
 
 namespace {
 
@@ -423,12 +424,11 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
     if (!(grad && g.WP == 64 && P.acc_lds && n.act == PINN_ACT_TANH)) { set_error("fused engine: no dropout kernel for this request"); return PINN_ERR_UNSUPPORTED; }
     rc = launch_fused_drop64(n.K1, P, grid, lds, s);
   }
-  else if (!rq && !grad && !coop && n.K1 == 1 && g.WP == 64 && Y && !dY && n.fused_kernel == FUSED_KERNEL_AUTO &&
-           P.n_tiles >= (int64_t)32 * cu_count()) {
-    // pinn_forward on enough points to give every wave of the chip (two per SIMD) a pass of four tiles: the plain
-    // forward's own kernel, one weight fetch per 64 points (pinn_fused_plain_w64.hip)
-    const int64_t want = ((P.n_tiles + 3) / 4 + FUSED_WAVES - 1) / FUSED_WAVES, cap = 2 * (int64_t)cu_count();
-    rc = launch_fused_plain64(P, (int)(want < cap ? want : cap), s);
+  else if (!rq && !grad && !coop && !batch && n.K1 == 1 && Y && !dY && n.fused_kernel == FUSED_KERNEL_AUTO &&
+           P.n_tiles >= fused_plain_min_tiles(g.WP, cu_count())) {
+    // pinn_forward on enough points to give every wave the chip holds a pass of four tiles: the plain forward's own
+    // kernel, one weight fetch per 64 points (pinn_fused_plain_w64.hip)
+    rc = launch_fused_plain(g.WP, P, cu_count(), s);
   }
   else if (batch) rc = g.WP == 16 ? launch_fused_batch<16>(n.W, n.d_in, n.K1, P, grid, lds, s)
                              : launch_fused_batch<32>(n.W, n.d_in, n.K1, P, grid, lds, s);

@@ -1,5 +1,5 @@
 // pinn_fused_plain_w64.hip — the PLAIN forward (pinn_forward: DNN.forward, dnn.py:54-55; test.py:76,96 evaluates grids of
-// points with it) at padded hidden width 64, FOUR 16-point tiles per wave and pass.
+// points with it), FOUR 16-point tiles per wave and pass (padded hidden width 16 / 32 / 64; the file keeps its first name).
 //
 // k_fused<64, 1, false, ...> runs one 16-column GEMM per weight block: every 16-point tile re-streams each layer's 16 KB of
 // weights (~20 TB/s of L2 reads chip-wide at 2^20 points per ms), and the weight loads' issue sits between 64-MFMA blocks.
@@ -11,9 +11,11 @@
 
 namespace pinn {
 
-template <int ACT>
-__global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_plain4(const FusedParams P) {
-  constexpr int WP = 64, NTH = WP / 16, C = 4;
+constexpr int plain4_occ(int WP) { return WP == 64 ? 2 : 4; }     // workgroups per CU = waves per SIMD the instance is built for
+
+template <int WP, int ACT>
+__global__ __launch_bounds__(FUSED_THREADS, plain4_occ(WP)) void k_fused_plain4(const FusedParams P) {
+  constexpr int NTH = WP / 16, C = 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = lane & 15, q = lane >> 4;
   const int64_t gw = (int64_t)blockIdx.x * FUSED_WAVES + wave, nw = (int64_t)gridDim.x * FUSED_WAVES;
@@ -94,10 +96,21 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_plain4(const FusedPa
   }
 }
 
-int launch_fused_plain64(const FusedParams& P, int grid, hipStream_t s) {
-  if (P.act == PINN_ACT_TANH) hipLaunchKernelGGL(k_fused_plain4<PINN_ACT_TANH>, dim3(grid), dim3(FUSED_THREADS), 0, s, P);
-  else hipLaunchKernelGGL(k_fused_plain4<PINN_ACT_LEAKY_RELU>, dim3(grid), dim3(FUSED_THREADS), 0, s, P);
-  return check_launch("fused plain-forward kernel (WP=64, four tiles per wave)");
+template <int WP>
+static int launch_plain(const FusedParams& P, int64_t n_tiles, int cus, hipStream_t s) {
+  const int64_t want = ((n_tiles + 3) / 4 + FUSED_WAVES - 1) / FUSED_WAVES, cap = (int64_t)plain4_occ(WP) * cus;
+  const int grid = (int)(want < cap ? want : cap);
+  if (P.act == PINN_ACT_TANH) hipLaunchKernelGGL((k_fused_plain4<WP, PINN_ACT_TANH>), dim3(grid), dim3(FUSED_THREADS), 0, s, P);
+  else hipLaunchKernelGGL((k_fused_plain4<WP, PINN_ACT_LEAKY_RELU>), dim3(grid), dim3(FUSED_THREADS), 0, s, P);
+  return check_launch("fused plain-forward kernel (four tiles per wave)");
+}
+
+// tiles below which the one-tile kernel spreads the points better: one pass of four tiles for every wave the chip holds
+int64_t fused_plain_min_tiles(int WP, int cus) { return (int64_t)4 * FUSED_WAVES * plain4_occ(WP) * cus; }
+
+int launch_fused_plain(int WP, const FusedParams& P, int cus, hipStream_t s) {
+  return WP == 16 ? launch_plain<16>(P, P.n_tiles, cus, s) : WP == 32 ? launch_plain<32>(P, P.n_tiles, cus, s)
+                                                                        : launch_plain<64>(P, P.n_tiles, cus, s);
 }
 
 }  // namespace pinn
