@@ -7,7 +7,7 @@
 namespace pinn {
 
 int launch_fused_drop64(int K1, const FusedParams& P, int grid, size_t lds, hipStream_t s);   // pinn_fused_w64_drop.hip
-int launch_fused_plain(int WP, const FusedParams& P, int cus, hipStream_t s);                      // pinn_fused_plain_w64.hip
+int launch_fused_plain(int WP, const FusedParams& P, int cus, hipStream_t s);                      // pinn_fused_plain.hip
 int64_t fused_plain_min_tiles(int WP, int cus);
 
 namespace {
@@ -427,7 +427,7 @@ int run(const Net& n, bool grad, const LossReq* rq, const float* params, const f
   else if (!rq && !grad && !coop && !batch && n.K1 == 1 && Y && !dY && n.fused_kernel == FUSED_KERNEL_AUTO &&
            P.n_tiles >= fused_plain_min_tiles(g.WP, cu_count())) {
     // pinn_forward on enough points to give every wave the chip holds a pass of four tiles: the plain forward's own
-    // kernel, one weight fetch per 64 points (pinn_fused_plain_w64.hip)
+    // kernel, one weight fetch per 64 points (pinn_fused_plain.hip)
     rc = launch_fused_plain(g.WP, P, cu_count(), s);
   }
   else if (batch) rc = g.WP == 16 ? launch_fused_batch<16>(n.W, n.d_in, n.K1, P, grid, lds, s)

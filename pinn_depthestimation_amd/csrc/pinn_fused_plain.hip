@@ -1,5 +1,5 @@
-// pinn_fused_plain_w64.hip — the PLAIN forward (pinn_forward: DNN.forward, dnn.py:54-55; test.py:76,96 evaluates grids of
-// points with it), FOUR 16-point tiles per wave and pass (padded hidden width 16 / 32 / 64; the file keeps its first name).
+// pinn_fused_plain.hip — the PLAIN forward (pinn_forward: DNN.forward, dnn.py:54-55; test.py:76,96 evaluates grids of
+// points with it), FOUR 16-point tiles per wave and pass (padded hidden width 16 / 32 / 64).
 //
 // k_fused<64, 1, false, ...> runs one 16-column GEMM per weight block: every 16-point tile re-streams each layer's 16 KB of
 // weights (~20 TB/s of L2 reads chip-wide at 2^20 points per ms), and the weight loads' issue sits between 64-MFMA blocks.

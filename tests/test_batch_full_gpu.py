@@ -53,7 +53,7 @@ def test_full_batch_instances_match_the_tile_kernel(name):
                                    (2, 6, 10, 10, 0), (2, 3, 100, 20, 0), (4, 4, 20, 20, 0), (3, 5, 2, 7, 1), (1, 1, 1, 32, 0)])
 def test_plain_forward_four_tiles_per_wave_is_bitwise_the_tile_kernel(shape):
     """pinn_forward above 131 072 points at padded width 64 (262 144 at 16 / 32) runs k_fused_plain4
-    (pinn_fused_plain_w64.hip: four tiles per wave share each weight fetch).  Same fmaf chain per point as the one-tile kernel: Y must be bit-identical
+    (pinn_fused_plain.hip: four tiles per wave share each weight fetch).  Same fmaf chain per point as the one-tile kernel: Y must be bit-identical
     (ragged point count: the last pass has one live tile and a half-empty one), and it must agree with the generic kernels."""
     from pinn_depthestimation_amd._lib import ENGINE_AUTO, ENGINE_GENERIC
     d_in, d_out, L, W, act = shape
