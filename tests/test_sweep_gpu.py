@@ -134,6 +134,8 @@ def draw_net(seed):
     W = r.choice(WIDTHS + WIDE_WIDTHS[:5] if seed % 3 else WIDTHS)
     L = r.choice([1, 2, 3, 5, 8, 12])
     N = r.choice(POINTS[:8])
+    if seed % 4 == 0 and W <= 64:
+        N = r.choice([150001, 300001])      # the plain forward's four-tiles-per-wave kernel (pinn_fused_plain.hip) takes over up here
     return d_in, d_out, gc, L, W, N
 
 
