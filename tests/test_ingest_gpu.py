@@ -59,3 +59,28 @@ def test_staged_points_feed_the_engine():
     flat = init_flat_params(desc.layers, "xavier", torch.Generator().manual_seed(0)).cuda()
     eng = Engine(desc)
     assert torch.equal(eng.forward(flat, X.contiguous()), eng.forward(flat, host))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_grids_stage_bit_identically(seed):
+    """Seeded sweep over grid shape, sub-sampling strides, NaN density (none .. everything), variable count and order:
+    the device path equals the host NumPy path bit for bit."""
+    import warnings
+    rng = np.random.RandomState(seed)
+    ny, nx = int(rng.choice([1, 2, 3, 17, 64, 129, 300])), int(rng.choice([1, 2, 5, 33, 256, 517, 1031]))
+    ix, iy = int(rng.randint(1, 6)), int(rng.randint(1, 6))
+    nan_frac = float(rng.choice([0.0, 0.0, 0.01, 0.2, 0.9, 1.0]))
+    g = grids(ny, nx, 77 + seed, nan_frac)
+    names = list(rng.permutation(["t", "x", "y", "h"])[:rng.randint(1, 5)])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mm = D.op.get_min_max({k: g[k] for k in names}, CFG)
+        host = D.residual_from_grids(g, names, mm, ix, iy)
+    want = torch.tensor(host).float()
+    X, mm_dev = D.stage_residual_on_device(g, names, CFG, None, ix, iy)
+    assert tuple(X.shape) == tuple(want.shape), (X.shape, want.shape)
+    assert torch.equal(X.cpu(), want)
+    for c, k in enumerate(names):
+        lo, hi = mm_dev[c].tolist()
+        assert (np.isnan(lo) and np.isnan(mm[k][0])) or lo == float(mm[k][0])
+        assert (np.isnan(hi) and np.isnan(mm[k][1])) or hi == float(mm[k][1])
