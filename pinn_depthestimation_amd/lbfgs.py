@@ -122,11 +122,11 @@ class _HipHistory:
 
 
 def _make_history(m: int, like: torch.Tensor):
+    # fp32 parameters on the GPU (the product path): csrc/pinn_lbfgs.hip, and a missing library is an error, not a
+    # reason to run something else.  _History (torch operators) serves CPU tensors and float64 — the CPU tests of the
+    # optimizer's semantics against torch.optim.LBFGS — and history sizes beyond the kernels' 256 (the reference: 100).
     if like.is_cuda and like.dtype == torch.float32 and m <= 256:
-        try:
-            return _HipHistory(m, like)
-        except Exception:                 # library not built: the torch formulation below is the same arithmetic
-            pass
+        return _HipHistory(m, like)
     return _History(m, like)
 
 
