@@ -1,8 +1,9 @@
 """Debug helper next to tests/test_sweep_gpu.py: one hand-given case, every fused kernel against the generic engine,
-gradient differences per parameter block.   python tools/sweep_debug.py RESIDUAL D_IN D_OUT L W K N [runs]
+gradient differences per parameter block.   python tests/devtools/sweep_debug.py RESIDUAL D_IN D_OUT L W K N [runs]
 (INN / OUTN / GC in the environment: comma lists overriding the column names and the differentiated columns)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 import torch
 from pinn_depthestimation_amd import Engine, NetDesc, ResidualSpec
 from pinn_depthestimation_amd._lib import ENGINE_AUTO, ENGINE_FUSED_BATCH, ENGINE_FUSED_COOP, ENGINE_FUSED_TILE, ENGINE_GENERIC
@@ -38,7 +39,7 @@ def run(e):
     return s.double().cpu(), grad.double().cpu()
 s0, g0 = run(ENGINE_GENERIC)
 if os.environ.get("ORACLE"):          # fp64 CPU oracle (checker only) as the comparator instead of the generic engine
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     from golden_util import oracle_loss_and_grad
     from oracle import pinn_oracle as O
     pl = O.unflatten(params.cpu(), base.layers)

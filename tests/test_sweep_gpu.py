@@ -5,7 +5,7 @@ batches, full batches) — every fused kernel that takes the case (AUTO's pick, 
 GENERIC engine (one thread per point, no MFMA, no shared code beyond residuals.h; itself pinned by the oracle in
 test_engine_gpu.py) on the same device buffers.  fp32 both sides: sums 1e-4 (summation order), gradient 1e-4 rel-L2 — the
 generic kernels' own fp32 accumulation is the noisier side (continuity_only, 20 000 points: generic 2.2e-5 from the fp64
-oracle, the fused kernels 7e-8; tools/sweep_debug.py) and a wrong kernel is off by >= 1e-2.
+oracle, the fused kernels 7e-8; tests/devtools/sweep_debug.py) and a wrong kernel is off by >= 1e-2.
 
 The committed seed ranges run in seconds; the same draws over 1 200 seeds (ranges widened by hand) pass as well.
 physics_equation cases scale the output layer by 0.25: with eta_mean + h near 0 the residual's 1 / (rho (eta_mean + h))
