@@ -5,7 +5,7 @@ import torch
 from oracle import pinn_oracle as O
 from pinn_depthestimation_amd import Engine, NetDesc, ResidualSpec
 from pinn_depthestimation_amd._lib import ENGINE_WIDE, PREC_BF16, PREC_F32
-from tests.test_engine_gpu import oracle_loss_and_grad, rel_l2
+from tests.golden_util import oracle_loss_and_grad, rel_l2
 
 CASES = {
     "ns_2x256": (3, 4, 2, 256, (0, 1, 2), "Navier_Stokes", ("t", "x", "y"), ("h", "z", "u", "v")),

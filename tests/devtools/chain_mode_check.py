@@ -5,7 +5,7 @@ import torch
 from oracle import pinn_oracle as O
 from pinn_depthestimation_amd import Engine, NetDesc, ResidualSpec
 from pinn_depthestimation_amd._lib import ENGINE_WIDE, PREC_BF16
-from tests.test_engine_gpu import oracle_loss_and_grad, rel_l2
+from tests.golden_util import oracle_loss_and_grad, rel_l2
 for (L, W) in ((2, 256), (3, 128), (3, 256)):
     for N in (160, 70, 1237):
         g = torch.Generator().manual_seed(4321)
