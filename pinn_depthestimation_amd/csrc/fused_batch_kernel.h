@@ -180,11 +180,29 @@ __device__ __forceinline__ void bunspill(const float* __restrict__ slot, float (
 //                        read by the caller before its VALU work.  dw[MT][NT] += sum_c sum_points Z (x) A;
 //                        bs[MT] += this lane's share of sum_points Z[0][MT] (lane groups combined at flush time).
 // Pads of quantity c: tb + c*(MT_N+NT_N) KB, Z tiles first.  One wave's LDS operations execute in order: no barrier.
+// pad layout of the weight-gradient operands: fused_kernel.h's second one (feature-major rows, PINN_FUSED_TR2) or the first
+#ifndef PINN_BATCH_TR2
+#define PINN_BATCH_TR2 PINN_FUSED_TR2
+#endif
+__device__ __forceinline__ void btr_write(float* __restrict__ tb, f4 v, int p, int q) {
+#if PINN_BATCH_TR2
+  transpose_write2(tb, v, p, q);
+#else
+  transpose_write(tb, v, p, q);
+#endif
+}
+__device__ __forceinline__ f4 btr_read(const float* __restrict__ tb, int p, int q) {
+#if PINN_BATCH_TR2
+  return transpose_read2(tb, p, q);
+#else
+  return transpose_read(tb, p, q);
+#endif
+}
 template <int NT, int KS>
 __device__ __forceinline__ void bwg_write_ks(float* __restrict__ tbq, const float (&v)[KS], int p, int q) {
 #pragma unroll
   for (int kt = 0; kt < NT; ++kt)
-    transpose_write(tbq + kt * TB_FLOATS, f4{4 * kt < KS ? v[4 * kt < KS ? 4 * kt : 0] : 0.f,
+    btr_write(tbq + kt * TB_FLOATS, f4{4 * kt < KS ? v[4 * kt < KS ? 4 * kt : 0] : 0.f,
                                              4 * kt + 1 < KS ? v[4 * kt + 1 < KS ? 4 * kt + 1 : 0] : 0.f,
                                              4 * kt + 2 < KS ? v[4 * kt + 2 < KS ? 4 * kt + 2 : 0] : 0.f,
                                              4 * kt + 3 < KS ? v[4 * kt + 3 < KS ? 4 * kt + 3 : 0] : 0.f}, p, q);
@@ -192,9 +210,9 @@ __device__ __forceinline__ void bwg_write_ks(float* __restrict__ tbq, const floa
 template <int MT_N, int NT_N>
 __device__ __forceinline__ void bwg_read_q(f4 (&zt)[MT_N], f4 (&at)[NT_N], const float* __restrict__ tbq, int p, int q) {
 #pragma unroll
-  for (int MT = 0; MT < MT_N; ++MT) zt[MT] = transpose_read(tbq + MT * TB_FLOATS, p, q);
+  for (int MT = 0; MT < MT_N; ++MT) zt[MT] = btr_read(tbq + MT * TB_FLOATS, p, q);
 #pragma unroll
-  for (int NT = 0; NT < NT_N; ++NT) at[NT] = transpose_read(tbq + (MT_N + NT) * TB_FLOATS, p, q);
+  for (int NT = 0; NT < NT_N; ++NT) at[NT] = btr_read(tbq + (MT_N + NT) * TB_FLOATS, p, q);
 }
 // NACC accumulator sets (dw[a]): a single 16x16 block (width <= 16) would otherwise be ONE dependent MFMA chain,
 // 40 cycles per link instead of the 32 of the issue rate; the sets are summed at flush time.
@@ -506,7 +524,7 @@ __global__ __launch_bounds__(BATCH_THREADS, batch_occ(WP, K1)) void k_fused_batc
         loss_epilogue<K1, true, true, EPI>(P, out, G, sums, sm, sm_mse, tb, pt, ptc, valid, p, q);
 #pragma unroll
         for (int c = 0; c < K1; ++c) {
-          transpose_write(tb + c * (1 + NTH) * TB_FLOATS, G[c][0], p, q);
+          btr_write(tb + c * (1 + NTH) * TB_FLOATS, G[c][0], p, q);
           bwg_write_ks<NTH, KS>(tb + (c * (1 + NTH) + 1) * TB_FLOATS, a[t][c], p, q);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -614,7 +632,7 @@ __global__ __launch_bounds__(BATCH_THREADS, batch_occ(WP, K1)) void k_fused_batc
           f4 xt;
 #pragma unroll
           for (int r = 0; r < 4; ++r) xt[r] = r < KS0 ? (c == 0 ? xin[t][r < KS0 ? r : 0] : tang[c][r < KS0 ? r : 0]) : 0.f;
-          transpose_write(tb + (c * (NTH + 1) + NTH) * TB_FLOATS, xt, p, q);
+          btr_write(tb + (c * (NTH + 1) + NTH) * TB_FLOATS, xt, p, q);
         }
         __builtin_amdgcn_sched_barrier(0);
         f4 ztr[2][NTH], xtr[2][1];
