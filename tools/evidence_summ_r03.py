@@ -15,7 +15,13 @@ src = os.path.join(root, "gpurun_out", "evidence_" + tag)
 dst = os.path.join(root, "profiles", "r03")
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"bench_{prefix}.json"))
-st = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
+def newest(pattern):
+    """gpurun MERGES the box's gpurun_out into the local one: files of earlier evidence runs of the same tag stay behind
+    under other PIDs.  Always take the newest."""
+    return sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]
+
+
+st = newest(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
 if st:
     shutil.copy(st[0], os.path.join(dst, f"{prefix}_kernel_stats.csv"))
 bench = json.load(open(os.path.join(src, "bench.json")))
@@ -24,7 +30,7 @@ names = {0: "fetch", 1: "write", 2: "sq", 3: "sq2"}
 per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))   # kernel -> counter -> values (per dispatch)
 n_adam = {}
 for i in range(4):
-    f = glob.glob(os.path.join(src, f"pmc_{i}", "*", "*counter_collection.csv"))
+    f = newest(os.path.join(src, f"pmc_{i}", "*", "*counter_collection.csv"))
     if not f:
         continue
     shutil.copy(f[0], os.path.join(dst, f"{prefix}_pmc_{names[i]}.csv"))
