@@ -20,6 +20,23 @@
 
 namespace pinn {
 
+// weight-gradient operand pads: fp32 mode uses fused_kernel.h's feature-major layout (one conflict-free ds_read_b128 per
+// block, PINN_FUSED_TR2); bf16 mode keeps the first layout (its operands are packed pairwise from consecutive points)
+#ifndef PINN_WIDE_TR2
+#define PINN_WIDE_TR2 PINN_FUSED_TR2
+#endif
+template <bool BF16>
+__device__ __forceinline__ void wtr_write(float* __restrict__ tb, f4 v, int p, int q) {
+  if constexpr (!BF16 && PINN_WIDE_TR2) transpose_write2(tb, v, p, q);
+  else transpose_write(tb, v, p, q);
+}
+template <bool BF16>
+__device__ __forceinline__ f4 wtr_read(const float* __restrict__ tb, int p, int q) {
+  if constexpr (!BF16 && PINN_WIDE_TR2) return transpose_read2(tb, p, q);
+  else return transpose_read<BF16>(tb, p, q);
+}
+
+
 constexpr int WIDE_WAVES = 4;
 constexpr int WIDE_THREADS = WIDE_WAVES * 64;
 constexpr int WIDE_MAX_PADS = 20;   // 4 zbar tiles + 16 input tiles of one quantity
@@ -365,15 +382,15 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_wgrad(const FusedParam
       for (int c = 0; c < K1; ++c) {
         float* ap = apad + buf * (NTN * TB_FLOATS);
 #pragma unroll
-        for (int MT = 0; MT < MTB; ++MT) transpose_write(zpad + MT * TB_FLOATS, rz[MT], p, q);
+        for (int MT = 0; MT < MTB; ++MT) wtr_write<BF16>(zpad + MT * TB_FLOATS, rz[MT], p, q);
 #pragma unroll
-        for (int i = 0; i < APW; ++i) transpose_write(ap + (wave * APW + i) * TB_FLOATS, ra[i], p, q);
+        for (int i = 0; i < APW; ++i) wtr_write<BF16>(ap + (wave * APW + i) * TB_FLOATS, ra[i], p, q);
         if (c + 1 < K1) fetch(t, c + 1);
         else if (t + nw < Lp.n_tiles) fetch(t + nw, 0);
         __syncthreads();
         f4 zt[MTB];
 #pragma unroll
-        for (int MT = 0; MT < MTB; ++MT) zt[MT] = transpose_read<BF16>(zpad + MT * TB_FLOATS, p, q);
+        for (int MT = 0; MT < MTB; ++MT) zt[MT] = wtr_read<BF16>(zpad + MT * TB_FLOATS, p, q);
         if (c == 0) {
 #pragma unroll
           for (int MT = 0; MT < MTB; ++MT) bs[MT] += (zt[MT][0] + zt[MT][1]) + (zt[MT][2] + zt[MT][3]);
@@ -382,7 +399,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_wgrad(const FusedParam
         for (int N0 = 0; N0 < NTN; N0 += 4) {
           f4 at[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) at[j] = transpose_read<BF16>(ap + (N0 + j) * TB_FLOATS, p, q);
+          for (int j = 0; j < 4; ++j) at[j] = wtr_read<BF16>(ap + (N0 + j) * TB_FLOATS, p, q);
           if constexpr (BF16) {
             bf16x4 a16[4];
 #pragma unroll
@@ -437,9 +454,9 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_wgrad(const FusedParam
       f4 zt[MTB], at[NTN];
       if (!AHEAD) fetch(t, c);
 #pragma unroll
-      for (int MT = 0; MT < MTB; ++MT) transpose_write(tb + MT * TB_FLOATS, rz[MT], p, q);
+      for (int MT = 0; MT < MTB; ++MT) wtr_write<BF16>(tb + MT * TB_FLOATS, rz[MT], p, q);
 #pragma unroll
-      for (int NT = 0; NT < NTN; ++NT) transpose_write(tb + (4 + NT) * TB_FLOATS, ra[NT], p, q);
+      for (int NT = 0; NT < NTN; ++NT) wtr_write<BF16>(tb + (4 + NT) * TB_FLOATS, ra[NT], p, q);
       // the raw registers are free again: start the next quantity's (or the next tile's) loads now
       if (AHEAD) {
         if (c + 1 < K1) fetch(t, c + 1);
@@ -448,9 +465,9 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_wide_wgrad(const FusedParam
       // fp32: element s <-> point 4s + q (one k-step of 16x16x4 per s);
       // bf16: element j <-> point 4q + j (the single k = 16 step of 16x16x16)
 #pragma unroll
-      for (int MT = 0; MT < MTB; ++MT) zt[MT] = transpose_read<BF16>(tb + MT * TB_FLOATS, p, q);
+      for (int MT = 0; MT < MTB; ++MT) zt[MT] = wtr_read<BF16>(tb + MT * TB_FLOATS, p, q);
 #pragma unroll
-      for (int NT = 0; NT < NTN; ++NT) at[NT] = transpose_read<BF16>(tb + (4 + NT) * TB_FLOATS, p, q);
+      for (int NT = 0; NT < NTN; ++NT) at[NT] = wtr_read<BF16>(tb + (4 + NT) * TB_FLOATS, p, q);
       if (c == 0) {
 #pragma unroll
         for (int MT = 0; MT < MTB; ++MT) bs[MT] += (zt[MT][0] + zt[MT][1]) + (zt[MT][2] + zt[MT][3]);
